@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the flame hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full frame of BASELINE.json configs[1] ("cfg2": 1920x1080 still, 3 xforms
+linear + spherical + swirl, 2^28 samples) through the drop-in entry point
+RenderManager.queue_frame: parameter interpolation, chaos-game iteration + flush, the filter
+chain (yuv -> bilateral DE -> logscale -> colorclip) and output conversion.  Frames are
+independent, so with N GPUs every rank renders its own frames (weak scaling, no collective
+in the data path) and the finished 8-bit frames are gathered to rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0:
+  value     = write-enabled chaos-game samples per second, whole job (Msamples/s)
+  roofline  = dominant kernel (k_iter): algorithmic 16 B/sample (8-byte read-modify-write of the
+              packed cell) x samples / HIP-event kernel time, vs the 8 TB/s HBM peak
+  cpu_baseline = the oracle's flam3-style chaos game on the host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(gnm, prof, seconds):
+    """flam3-style CPU chaos game (oracle/flame_ref.c ref_flam3_render) on a bounded sample."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from common import O, prepare
+    F = prepare(gnm, prof)
+    cores = os.cpu_count() or 1
+    probe = 1 << 22
+    _, secs, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], probe * cores, cores)
+    rate = probe * cores / max(secs, 1e-3)
+    n = int(max(probe * cores, min(2 ** 31, rate * seconds)))
+    _, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, cores)
+    return {'value': round(n / secs / 1e6, 3), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d samples of the cfg2 flame (1920x1080 histogram, per-thread private float4 '
+                      'accumulators merged at the end), %.1f s wall' % (n, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (0 = skip)')
+    ap.add_argument('--accum', default=os.environ.get('FLAME_ACCUM', 'atomic'))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    torch.cuda.set_device(local)
+
+    from cuburn_amd import configs, profile, render, _lib
+    gnm, prof = configs.CONFIGS[args.config]()
+    gprof = profile.wrap(prof, gnm)
+    mgr = render.RenderManager(device=local, nslots=1024, host_seed=42 + rank)
+    if args.accum == 'binned':
+        mgr.accum_mode = _lib.ACCUM_BINNED
+    rdr = render.Renderer(gnm, gprof)
+    w, h = gprof.width, gprof.height
+    frame = torch.empty((h, w, 4), dtype=torch.uint8, device='cuda')
+    gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
+    tc = 0.5
+
+    def step():
+        evt, h_out = mgr.queue_frame(rdr, gnm, gprof, tc)
+        if world > 1:
+            # finished frame -> device tensor -> RCCL gather to rank 0 (frames are the only exchange)
+            evt.synchronize()
+            frame.copy_(torch.from_numpy(h_out), non_blocking=False)
+            dist.gather(frame, gathered, dst=0)
+        return evt
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step().synchronize()
+    fence()
+    acc = dict(iter_ms=0.0, flush_ms=0.0, filter_ms=0.0, launches=0, samples=0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        evt = step()
+        evt.synchronize()
+        t = mgr.timings()
+        for k in ('iter_ms', 'flush_ms', 'filter_ms', 'launches'):
+            acc[k] += t[k]
+        acc['samples'] += mgr.last_nsamples
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        dim = render.Framebuffers.calc_dim(w, h)
+        nbins = dim.ah * dim.astride
+        samples_total = acc['samples'] * world            # every rank runs the same workload
+        iter_s = acc['iter_ms'] * 1e-3
+        achieved = 16.0 * acc['samples'] / iter_s / 1e9 if iter_s > 0 else 0.0
+        de_bytes = 512.0 * nbins * args.steps              # 64 B/px/direction x 8
+        out = {
+            'metric': 'Msamples/s into 1920x1080 histogram + DE-filter GB/s vs HBM roofline',
+            'value': round(samples_total / elapsed / 1e6, 2),
+            'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
+                                   '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
+                       'samples_per_frame': acc['samples'] // max(args.steps, 1),
+                       'accum': args.accum, 'frames_per_gpu': args.steps,
+                       'parallelism': 'frame-sharded x%d, RCCL gather' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'avg_launch_ms': round(acc['iter_ms'] / max(acc['launches'], 1), 4),
+                         'iter_msamples_per_s': round(acc['samples'] / iter_s / 1e6, 1) if iter_s > 0 else 0.0},
+            'de_filter': {'gbps': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9, 2) if acc['filter_ms'] > 0 else 0.0,
+                          'frac_of_peak': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if acc['filter_ms'] > 0 else 0.0,
+                          'note': 'algorithmic 512 B/px over the whole filter chain time (yuv+bilateral+logscale+colorclip)',
+                          'filter_ms_per_frame': round(acc['filter_ms'] / args.steps, 4)},
+            'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / args.steps, 4), 'flush': round(acc['flush_ms'] / args.steps, 4),
+                                    'filters': round(acc['filter_ms'] / args.steps, 4)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out['cpu_baseline'] = cpu_baseline(gnm, prof, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

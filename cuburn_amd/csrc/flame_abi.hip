@@ -1,0 +1,549 @@
+// flame_abi.hip — host side of libflame_hip.so: the C ABI of include/flame_hip.h.
+//
+// Holds what cuburn's RenderManager / Framebuffers / Renderer hold on the CUDA side
+// (cuburn/render.py:40-170, 225-262): device buffers, the stream, persistent walker and
+// RNG state, and the per-frame launch sequences of render.py:289-372 and filters.py.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const char *what, const char *file, int line, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    else snprintf(buf, sizeof buf, "%s (%s:%d)", what, file, line);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(e_ == hipErrorOutOfMemory ? FL_E_NOMEM : FL_E_HIP, #x, __FILE__, __LINE__, e_); } while (0)
+#define REQUIRE(c, msg) do { if (!(c)) return fail(FL_E_INVAL, msg, __FILE__, __LINE__); } while (0)
+
+struct EvPair { hipEvent_t a, b; };
+
+struct fl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t nslots = 0, nwalkers = 0;
+    int nw = 4;                       // waves per iterate workgroup
+    fl_mwc *d_rng = nullptr;          // [nwalkers]; last FL_PAL_H*256 serve the palette kernel
+    float4 *d_points = nullptr;       // [nslots*256]
+    size_t nbins = 0;
+    float4 *d_front = nullptr, *d_back = nullptr, *d_side = nullptr;
+    float *d_blur = nullptr;          // 1-channel scratch [nbins]
+    u64 *d_atom = nullptr;
+    uint32_t *d_hot = nullptr;
+    void *d_outpix = nullptr;         // w*h*8 bytes
+    size_t outpix_bytes = 0;
+    u64 *d_counters = nullptr;
+    float *d_params = nullptr;        // [FL_NTEMPORAL * FL_MAX_PSTRIDE]
+    u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
+    uint32_t round_counter = 0;
+    hipEvent_t ev_frame0 = nullptr, ev_last = nullptr;
+    std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev;
+    size_t pool_used = 0;
+    bool timing = true;
+};
+
+struct fl_genome {
+    std::vector<int32_t> prog;
+    uint32_t nops = 0, nrows = 0, pstride = 0;
+    int32_t *d_prog = nullptr, *d_ops = nullptr;
+    float *d_times = nullptr, *d_knots = nullptr, *d_ptimes = nullptr;
+    float4 *d_pals = nullptr;
+    uint32_t npal = 0;
+};
+
+static const int kKnownVars[] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,
+    34,35,36,37,38,39,40,41,42,43,44,45,46,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71,72,73,
+    74,75,76,77,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95,97,98};
+
+static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
+{
+    if (!c->timing) return nullptr;
+    if (c->pool_used == c->pool.size()) {
+        EvPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        c->pool.push_back(p);
+    }
+    EvPair p = c->pool[c->pool_used++];
+    list.push_back(p);
+    hipEventRecord(p.a, c->stream);
+    return &list.back();
+}
+static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, c->stream); }
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int fl_abi_version(void) { return FL_ABI_VERSION; }
+const char *fl_last_error(void) { return g_err.c_str(); }
+
+void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *o)
+{
+    o->w = w; o->h = h;
+    o->aw = w + 2 * FL_GUTTER;
+    o->ah = 16 * ((h + 2 * FL_GUTTER + 15) / 16);
+    o->astride = 32 * ((o->aw + 31) / 32);
+}
+
+static void free_fb(fl_ctx *c)
+{
+    hipFree(c->d_front); hipFree(c->d_back); hipFree(c->d_side); hipFree(c->d_blur);
+    hipFree(c->d_atom); hipFree(c->d_hot); hipFree(c->d_outpix);
+    c->d_front = c->d_back = c->d_side = nullptr; c->d_blur = nullptr; c->d_atom = nullptr;
+    c->d_hot = nullptr; c->d_outpix = nullptr; c->nbins = 0; c->outpix_bytes = 0;
+}
+
+// cuburn/render.py:121-161 Framebuffers.alloc / set_dim: grow-only; on OOM free everything
+// and report FL_E_NOMEM so the caller survives an oversize frame.
+static int ensure_fb(fl_ctx *c, const fl_dim &d)
+{
+    size_t nbins = (size_t)d.ah * d.astride, ob = (size_t)d.w * d.h * 8;
+    if (c->nbins >= nbins && c->outpix_bytes >= ob) return FL_OK;
+    hipStreamSynchronize(c->stream);
+    free_fb(c);
+    hipError_t e;
+    if ((e = hipMalloc(&c->d_front, 16 * nbins)) || (e = hipMalloc(&c->d_back, 16 * nbins)) ||
+        (e = hipMalloc(&c->d_side, 16 * nbins)) || (e = hipMalloc(&c->d_blur, 4 * nbins)) ||
+        (e = hipMalloc(&c->d_atom, 8 * nbins)) || (e = hipMalloc(&c->d_hot, 4 * (nbins / 16))) ||
+        (e = hipMalloc(&c->d_outpix, ob))) {
+        free_fb(c);
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? FL_E_NOMEM : FL_E_HIP, "framebuffer allocation", __FILE__, __LINE__, e);
+    }
+    c->nbins = nbins; c->outpix_bytes = ob;
+    return FL_OK;
+}
+
+int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nslots, fl_ctx **out)
+{
+    REQUIRE(out && seeds, "null argument");
+    REQUIRE(nslots >= FL_NTEMPORAL && (nslots & (nslots - 1)) == 0, "nslots must be a power of two >= 1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FL_E_NODEV, "no HIP device", __FILE__, __LINE__);
+    REQUIRE(device >= 0 && device < ndev, "bad device index");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FL_E_NODEV, "device is not gfx950 (kernels are built for MI355X only)", __FILE__, __LINE__);
+    fl_ctx *c = new fl_ctx;
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->nslots = nslots;
+    c->nwalkers = (nslots + FL_PAL_H) * 256;
+    const char *env_nw = getenv("FLAME_NW");
+    if (env_nw && atoi(env_nw) == 8) c->nw = 8;
+    HIPCHK(hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers));
+    HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * 256));
+    HIPCHK(hipMalloc(&c->d_counters, 8 * 4));
+    HIPCHK(hipMalloc(&c->d_params, sizeof(float) * FL_NTEMPORAL * FL_MAX_PSTRIDE));
+    HIPCHK(hipMalloc(&c->d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W));
+    HIPCHK(hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * 256 * 4));
+    HIPCHK(hipMemset(c->d_counters, 0, 32));
+    HIPCHK(hipEventCreate(&c->ev_frame0));
+    HIPCHK(hipEventCreate(&c->ev_last));
+    *out = c;
+    return FL_OK;
+}
+
+void fl_ctx_destroy(fl_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_fb(c);
+    hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters); hipFree(c->d_params); hipFree(c->d_palette);
+    for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    hipEventDestroy(c->ev_frame0); hipEventDestroy(c->ev_last);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int fl_ctx_sync(fl_ctx *c) { REQUIRE(c, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return FL_OK; }
+
+// Validate the xform program before any kernel trusts it (the reference traps on device,
+// cuburn/code/iter.py:254-257).
+static int check_prog(const int32_t *p, uint32_t n)
+{
+    REQUIRE(n >= FL_PROG_HDR + 1 && p[0] == FL_PROG_MAGIC, "bad program header");
+    int nxf = p[1], hf = p[2], ps = p[3], cdf = p[4];
+    REQUIRE(nxf >= 1 && nxf <= FL_MAX_XFORMS && (hf == 0 || hf == 1), "bad xform count");
+    REQUIRE(ps >= 6 + nxf && ps <= FL_MAX_PSTRIDE, "bad pstride");
+    REQUIRE(cdf >= 6 && cdf + nxf <= ps, "bad cdf offset");
+    REQUIRE(n >= (uint32_t)(FL_PROG_HDR + nxf + hf), "truncated descriptor table");
+    for (int i = 0; i < nxf + hf; ++i) {
+        int off = p[FL_PROG_HDR + i];
+        REQUIRE(off >= FL_PROG_HDR + nxf + hf && (uint32_t)off + 3 <= n, "descriptor offset out of range");
+        const int32_t *d = p + off;
+        int rec = 8 + ((d[1] & 1) ? 6 : 0);
+        REQUIRE(d[0] >= 6 && d[0] + rec <= ps, "xform record out of range");
+        REQUIRE(d[2] >= 0 && (uint32_t)off + 3 + 2 * (uint32_t)d[2] <= n, "variation list out of range");
+        for (int j = 0; j < d[2]; ++j) {
+            int id = d[3 + 2 * j], vo = d[4 + 2 * j];
+            bool known = false;
+            for (int k : kKnownVars) known |= (k == id);
+            if (!known) return fail(FL_E_UNSUPPORTED, "unknown variation id", __FILE__, __LINE__);
+            REQUIRE(vo >= 6 && vo + 9 <= ps + 8 && vo < ps, "variation record out of range");
+        }
+    }
+    return FL_OK;
+}
+
+int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops,
+                     uint32_t nrows, fl_genome **out)
+{
+    REQUIRE(c && prog && ops && out, "null argument");
+    int rc = check_prog(prog, nprog);
+    if (rc) return rc;
+    REQUIRE(nrows >= 1 && nrows <= 4096 && nops >= 1, "bad row / op count");
+    uint32_t ps = prog[3];
+    for (uint32_t i = 0; i < nops; ++i) {
+        const int32_t *o = ops + 4 * i;
+        REQUIRE(o[0] >= FL_OP_SPLINE && o[0] <= FL_OP_INVSQ_MAX, "bad op kind");
+        REQUIRE(o[1] >= 0 && (uint32_t)o[1] < ps && o[2] >= 0 && (uint32_t)o[2] < nrows, "op out of range");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    fl_genome *g = new fl_genome;
+    g->prog.assign(prog, prog + nprog);
+    g->nops = nops; g->nrows = nrows; g->pstride = ps;
+    HIPCHK(hipMalloc(&g->d_prog, 4 * nprog));
+    HIPCHK(hipMalloc(&g->d_ops, 16 * nops));
+    HIPCHK(hipMalloc(&g->d_times, 4 * (size_t)nrows * FL_KNOTS));
+    HIPCHK(hipMalloc(&g->d_knots, 4 * (size_t)nrows * FL_KNOTS));
+    HIPCHK(hipMalloc(&g->d_ptimes, 4 * FL_KNOTS));
+    HIPCHK(hipMalloc(&g->d_pals, 16 * 256 * FL_KNOTS));
+    HIPCHK(hipMemcpy(g->d_prog, prog, 4 * nprog, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->d_ops, ops, 16 * nops, hipMemcpyHostToDevice));
+    *out = g;
+    return FL_OK;
+}
+
+void fl_genome_destroy(fl_genome *g)
+{
+    if (!g) return;
+    hipFree(g->d_prog); hipFree(g->d_ops); hipFree(g->d_times); hipFree(g->d_knots);
+    hipFree(g->d_ptimes); hipFree(g->d_pals);
+    delete g;
+}
+
+int fl_genome_upload(fl_ctx *c, fl_genome *g, const float *times, const float *knots,
+                     const float *pal_rgba, const float *pal_times, uint32_t npal)
+{
+    REQUIRE(c && g && times && knots && pal_rgba && pal_times, "null argument");
+    REQUIRE(npal >= 1 && npal < FL_KNOTS, "bad palette count");
+    size_t nb = 4 * (size_t)g->nrows * FL_KNOTS;
+    // synchronous copies: the host arrays are ordinary (pageable) numpy memory
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(g->d_times, times, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->d_knots, knots, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(g->d_pals, 0, 16 * 256 * FL_KNOTS));
+    HIPCHK(hipMemcpy(g->d_pals, pal_rgba, 16 * 256 * (size_t)npal, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->d_ptimes, pal_times, 4 * FL_KNOTS, hipMemcpyHostToDevice));
+    g->npal = npal;
+    return FL_OK;
+}
+
+int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float td)
+{
+    REQUIRE(c && g && g->npal, "genome not uploaded");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    // new frame: restart the measurement lists
+    c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
+    HIPCHK(hipEventRecord(c->ev_frame0, c->stream));
+    fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * 256;
+    launch_interp_palette(c->stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, c->d_palette);
+    launch_interp_params(c->stream, c->d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
+                         ts, td / FL_NTEMPORAL, d);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
+{
+    size_t nbins = (size_t)d.ah * d.astride;
+    // cuburn/render.py:321-328
+    HIPCHK(hipMemsetAsync(c->d_front, 0, 16 * nbins, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_atom, 0, 8 * nbins, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_hot, 0, 4 * (nbins / 16), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * 256 * 4, c->stream));
+    return FL_OK;
+}
+
+static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count)
+{
+    EvPair *e = ev_begin(c, c->iter_ev);
+    launch_iter(c->stream, c->nw, count, c->nslots, g->d_prog, c->d_params, c->d_palette, c->d_rng, c->d_points,
+                c->d_hot, c->d_atom, (float *)c->d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse);
+    ev_end(c, e);
+    c->round_counter += nrounds;
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+static int do_flush(fl_ctx *c, const fl_dim &d)
+{
+    EvPair *e = ev_begin(c, c->flush_ev);
+    launch_flush(c->stream, c->d_atom, c->d_front, c->d_hot, d.ah * d.astride);
+    ev_end(c, e);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples, uint32_t fuse,
+               int accum_mode, uint64_t *nsamples_run)
+{
+    REQUIRE(c && g, "null argument");
+    REQUIRE(accum_mode == FL_ACCUM_ATOMIC, "accumulation mode not available");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    if ((rc = do_clear(c, d, true))) return rc;
+    const uint32_t nt = (uint32_t)c->nw * 64;
+    const double per_round = (double)c->nslots * nt;
+    uint64_t rounds = (uint64_t)ceil(nsamples / per_round);
+    if (rounds == 0) rounds = 1;
+    if (nsamples_run) *nsamples_run = (uint64_t)(rounds * per_round);
+    // cuburn/render.py:338-369: launch batches grow 4, 6, 9, 13, ... (x 256 rounds), each
+    // followed by a flush; the first batch also carries the fuse rounds.
+    uint64_t batch = 4;
+    bool first = true;
+    while (rounds) {
+        uint64_t n = rounds < batch * 256 ? rounds : batch * 256;
+        uint32_t f = first ? fuse : 0;
+        if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false))) return rc;
+        if ((rc = do_flush(c, d))) return rc;
+        rounds -= n;
+        batch += batch / 2;
+        first = false;
+    }
+    return FL_OK;
+}
+
+static void gauss7(float stdev, float *c)      // cuburn/filters.py:11-16
+{
+    float s = 0.0f;
+    for (int i = 0; i < 7; ++i) { float x = (float)(i - 3); c[i] = expf(x * x / (-2.0f * stdev * stdev)); s += c[i]; }
+    for (int i = 0; i < 7; ++i) c[i] /= s;
+}
+
+int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_t np)
+{
+    REQUIRE(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    float k7[7];
+    EvPair *e = ev_begin(c, c->filt_ev);
+    switch (id) {
+    case FL_FILT_YUV:
+        launch_yuv_to_rgb(st, d, c->d_back, c->d_front);
+        std::swap(c->d_front, c->d_back);
+        break;
+    case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
+        REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
+        gauss7(1.0f, k7);
+        for (int pat = 0; pat < 8; ++pat) {
+            launch_den_blur(st, d, c->d_blur, c->d_front, pat, 0, k7);
+            launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, pat, 1, k7);
+            launch_bilateral(st, d, c->d_back, c->d_front, (const float *)c->d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
+            std::swap(c->d_front, c->d_back);
+        }
+    } break;
+    case FL_FILT_LOGSCALE:
+        REQUIRE(np >= 2, "logscale needs k1,k2");
+        launch_logscale(st, d, c->d_front, p[0], p[1]);
+        break;
+    case FL_FILT_COLORCLIP:
+        REQUIRE(np >= 5, "colorclip needs vib,highpow,gam,lin,lingam");
+        launch_colorclip(st, d, c->d_front, p[0], p[1], p[2], p[3], p[4]);
+        break;
+    case FL_FILT_SMEARCLIP:              // cuburn/filters.py:142-163
+        REQUIRE(np >= 4, "smearclip needs width,gam_m_1,lin,lingam");
+        gauss7(p[0], k7);
+        launch_gamma_full_hi(st, d, c->d_side, c->d_front);
+        launch_full_blur(st, d, c->d_back, c->d_side, 2, 0, k7);
+        launch_full_blur(st, d, c->d_side, c->d_back, 3, 0, k7);
+        launch_full_blur(st, d, c->d_back, c->d_side, 0, 0, k7);
+        launch_full_blur(st, d, c->d_side, c->d_back, 1, 0, k7);
+        launch_smearclip(st, d, c->d_front, c->d_side, p[1], p[2], p[3]);
+        break;
+    case FL_FILT_HALOCLIP:               // cuburn/filters.py:113-130
+        REQUIRE(np >= 1, "haloclip needs gam_m_1");
+        gauss7(1.0f, k7);
+        launch_apply_gamma(st, d, c->d_blur, c->d_front, 0.1f);
+        launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, 2, 0, k7);
+        launch_den_blur_1c(st, d, c->d_blur, (const float *)c->d_side, 3, 0, k7);
+        launch_haloclip(st, d, c->d_front, c->d_blur, p[0]);
+        break;
+    case FL_FILT_PLAINCLIP:
+        REQUIRE(np >= 4, "plainclip needs gam_m_1,lin,lingam,brightness");
+        launch_plainclip(st, d, c->d_front, p[0], p[1], p[2], p[3]);
+        break;
+    case FL_FILT_LOGENCODE:
+        REQUIRE(np >= 1, "logencode needs degamma");
+        launch_logencode(st, d, c->d_back, c->d_front, p[0]);
+        std::swap(c->d_front, c->d_back);
+        break;
+    default:
+        return fail(FL_E_UNSUPPORTED, "unknown filter id", __FILE__, __LINE__);
+    }
+    ev_end(c, e);
+    HIPCHK(hipGetLastError());
+    return FL_OK;
+}
+
+int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out)
+{
+    REQUIRE(c && (fmt == 0 || fmt == 1), "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    void *dst = dev_out ? (void *)(uintptr_t)dev_out : c->d_outpix;
+    launch_f32_to_rgba(c->stream, d, c->d_front, c->d_rng, c->nslots * 256, fmt, dst);
+    HIPCHK(hipGetLastError());
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_last, c->stream));
+    return FL_OK;
+}
+
+int fl_frame_ms(fl_ctx *c, float *ms)
+{
+    REQUIRE(c && ms, "null argument");
+    HIPCHK(hipEventRecord(c->ev_last, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev_last));
+    HIPCHK(hipEventElapsedTime(ms, c->ev_frame0, c->ev_last));
+    return FL_OK;
+}
+
+static float sum_ms(std::vector<EvPair> &v)
+{
+    float t = 0.0f;
+    for (auto &p : v) { float ms = 0.0f; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) t += ms; }
+    return t;
+}
+
+int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *nlaunch)
+{
+    REQUIRE(c, "null ctx");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (iter_ms) *iter_ms = sum_ms(c->iter_ev);
+    if (flush_ms) *flush_ms = sum_ms(c->flush_ev);
+    if (filter_ms) *filter_ms = sum_ms(c->filt_ev);
+    if (nlaunch) *nlaunch = (uint32_t)c->iter_ev.size();
+    return FL_OK;
+}
+
+static int buf_ptr(fl_ctx *c, fl_genome *g, int which, void **p, size_t *cap)
+{
+    switch (which) {
+    case FL_BUF_FRONT: *p = c->d_front; *cap = 16 * c->nbins; break;
+    case FL_BUF_BACK: *p = c->d_back; *cap = 16 * c->nbins; break;
+    case FL_BUF_SIDE: *p = c->d_side; *cap = 16 * c->nbins; break;
+    case FL_BUF_PARAMS: *p = c->d_params; *cap = 4 * (size_t)FL_NTEMPORAL * (g ? g->pstride : FL_MAX_PSTRIDE); break;
+    case FL_BUF_PALETTE: *p = c->d_palette; *cap = 8 * FL_PAL_H * FL_PAL_W; break;
+    case FL_BUF_POINTS: *p = c->d_points; *cap = 16 * (size_t)c->nslots * 256; break;
+    case FL_BUF_SEEDS: *p = c->d_rng; *cap = sizeof(fl_mwc) * (size_t)c->nwalkers; break;
+    case FL_BUF_ATOM: *p = c->d_atom; *cap = 8 * c->nbins; break;
+    case FL_BUF_HOT: *p = c->d_hot; *cap = 4 * (c->nbins / 16); break;
+    default: return fail(FL_E_INVAL, "unknown buffer", __FILE__, __LINE__);
+    }
+    if (!*p) return fail(FL_E_INVAL, "buffer not allocated yet", __FILE__, __LINE__);
+    return FL_OK;
+}
+
+int fl_read_buffer(fl_ctx *c, fl_genome *g, int which, void *dst, size_t nbytes)
+{
+    REQUIRE(c && dst, "null argument");
+    void *p; size_t cap;
+    int rc = buf_ptr(c, g, which, &p, &cap);
+    if (rc) return rc;
+    REQUIRE(nbytes <= cap, "read larger than buffer");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dst, p, nbytes, hipMemcpyDeviceToHost));
+    return FL_OK;
+}
+
+int fl_write_buffer(fl_ctx *c, fl_genome *g, int which, const void *src, size_t nbytes)
+{
+    REQUIRE(c && src, "null argument");
+    void *p; size_t cap;
+    int rc = buf_ptr(c, g, which, &p, &cap);
+    if (rc) return rc;
+    REQUIRE(nbytes <= cap, "write larger than buffer");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice));
+    return FL_OK;
+}
+
+int fl_debug_clear(fl_ctx *c, uint32_t w, uint32_t h, int reset_points)
+{
+    REQUIRE(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    return do_clear(c, d, reset_points != 0);
+}
+
+int fl_debug_iter_launch(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, uint32_t round0,
+                         uint32_t nrounds, uint32_t fuse, int accum_mode)
+{
+    REQUIRE(c && g && accum_mode == FL_ACCUM_ATOMIC, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    c->round_counter = round0;
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    return do_iter_launch(c, g, d, nrounds, fuse, true);
+}
+
+int fl_debug_flush(fl_ctx *c, uint32_t w, uint32_t h)
+{
+    REQUIRE(c, "null ctx");
+    fl_dim d; fl_calc_dim(w, h, &d);
+    int rc = ensure_fb(c, d);
+    if (rc) return rc;
+    return do_flush(c, d);
+}
+
+int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)
+{
+    REQUIRE(c && out256, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t *d; const size_t n = (size_t)c->nw * 64;
+    HIPCHK(hipMalloc(&d, 4 * n));
+    launch_shuffle_tap(c->stream, c->nw, d, round);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out256, d, 4 * n, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return FL_OK;
+}
+
+int fl_debug_counters(fl_ctx *c, uint64_t out4[4])
+{
+    REQUIRE(c && out4, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out4, c->d_counters, 32, hipMemcpyDeviceToHost));
+    return FL_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

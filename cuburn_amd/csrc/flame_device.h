@@ -1,0 +1,65 @@
+// flame_device.h — device-side helpers shared by the gfx950 kernels: MWC RNG, packed
+// accumulator cell, fast math wrappers.  (Product code; independent of oracle/.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/flame_hip.h"
+
+typedef unsigned long long u64;
+
+// Float constants as spelled by the reference's device prelude (cuburn/code/util.py:148-160)
+#define FM_PI 3.14159274101257f
+#define FM_PI_2 1.57079637050629f
+#define FM_1_PI 0.31830987334251f
+#define FM_2_PI 0.63661974668503f
+#define FM_LOG2E 1.44269502162933f
+#define FM_SQRT2 1.41421353816986f
+#define FL_INV255 0.003921568859368562698f
+
+// ---- multiply-with-carry RNG, cuburn/code/mwc.py:56-77 -----------------------------------
+struct mwc_t { uint32_t mul, state, carry; };
+
+__device__ __forceinline__ uint32_t mwc_next(mwc_t &s) {
+    u64 t = (u64)s.mul * s.state + s.carry;       // v_mad_u64_u32
+    s.state = (uint32_t)t;
+    s.carry = (uint32_t)(t >> 32);
+    return s.state;
+}
+// u32 -> f32 round-to-nearest, times 2^-32 (may return exactly 1.0f, like the reference)
+__device__ __forceinline__ float mwc_next_01(mwc_t &s) { return (float)mwc_next(s) * (1.0f / 4294967296.0f); }
+__device__ __forceinline__ float mwc_next_11(mwc_t &s) { return (float)(int32_t)mwc_next(s) * (1.0f / 2147483648.0f); }
+
+// ---- packed 64-bit accumulator cell, include/flame_hip.h (3) -------------------------------
+__device__ __forceinline__ void unpack_cell(u64 cell, float &y, float &u, float &v, float &d) {
+    uint32_t hi = (uint32_t)(cell >> 32), lo = (uint32_t)cell;
+    d = (float)(hi >> 22);
+    y = (float)__builtin_amdgcn_ubfe(hi, 4, 18);
+    u = (float)(((hi & 0xfu) << 14) | (lo >> 18));
+    v = (float)(lo & 0x3ffffu);
+}
+// hot flag (0..3) -> sample weight 1, 2, 8, 32  (cuburn/code/iter.py:326)
+__device__ __forceinline__ float hot_mult(uint32_t flag) { return flag ? (float)((1u << (flag << 1)) >> 1) : 1.0f; }
+
+// ---- fast math, the forms nvcc -use_fast_math gives the reference (cuburn/code/util.py:96) ---
+__device__ __forceinline__ float fsin(float x) { return __sinf(x); }
+__device__ __forceinline__ float fcos(float x) { return __cosf(x); }
+__device__ __forceinline__ float ftan(float x) { return __fdividef(__sinf(x), __cosf(x)); }
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+__device__ __forceinline__ float flog2(float x) { return __log2f(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fpow(float x, float y) { return __powf(x, y); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ float frcp(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ float fsqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+
+// cvt.rni.s32.f32 (cuburn/code/util.py:194-200): round-to-nearest-even, saturating, NaN -> 0
+__device__ __forceinline__ uint32_t trunca(float f) {
+    float c = fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);      // NaN -> -2^31 here ...
+    int32_t i = (int32_t)__builtin_rintf(c);
+    if (f >= 2147483648.0f) i = 0x7fffffff;
+    return (f != f) ? 0u : (uint32_t)i;                              // ... and 0 here
+}
+
+// XCD id of the executing workgroup (HW_REG_XCC_ID, bits [3:0])
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7; }

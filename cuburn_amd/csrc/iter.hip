@@ -1,0 +1,234 @@
+// iter.hip — chaos-game iteration, packed-cell flush and hot-pixel flags for gfx950.
+//
+// Replaces the run-time generated `iter` / `flush_atom` kernels of the reference
+// (cuburn/code/iter.py:157-418, :420-544) with precompiled kernels that interpret the
+// xform program of include/flame_hip.h (5).  MI355X mapping:
+//   * workgroup = NW waves x 64 lanes, one walker per lane, bound to a persistent slot
+//     (slot = blockIdx.x; temporal sample = slot & 1023, palette row = that >> 4);
+//   * xform selection is per WAVE: every lane draws, lane 0's draw is broadcast with
+//     v_readfirstlane, so the xform branch and all parameter loads are scalar;
+//   * walkers change wave every round through a double-buffered LDS swap (one barrier per
+//     round), three-phase destination pattern so no pair shares a wave 3 rounds running;
+//   * samples are accumulated as 64-bit packed cells with global atomics whose returned
+//     value is examined one round later (latency hidden) to drain nearly-full cells.
+#include "variations.h"
+#include "kernels.h"
+
+template <int NW>
+__device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_t phase) {
+    uint32_t sh = l + (phase == 1 ? l / NW : 0u) + (phase == 2 ? l / (NW * NW) : 0u);
+    return ((w + sh) % NW) * 64u + l;
+}
+
+// cuburn/code/iter.py:121-149: pre affine, sum of variations, optional post affine, colour
+// blend.  `xfi` is wave-uniform; all prog[] / P[] reads are scalar.
+__device__ __forceinline__ void apply_xf(const int32_t *__restrict__ prog, const float *__restrict__ P,
+                                         int xfi, float &x, float &y, float &c, mwc_t &r)
+{
+    const int32_t *d = prog + prog[FL_PROG_HDR + xfi];
+    const float *xf = P + d[0];
+    const int nvar = d[2];
+    float tx = fmaf(xf[0], x, fmaf(xf[1], y, xf[2]));
+    float ty = fmaf(xf[3], x, fmaf(xf[4], y, xf[5]));
+    float ox = 0.0f, oy = 0.0f;
+    for (int j = 0; j < nvar; ++j)
+        apply_variation(d[3 + 2 * j], P + d[4 + 2 * j], xf, tx, ty, ox, oy, r);
+    const float *cp = xf + 6;
+    if (d[1] & 1) {
+        float qx = fmaf(cp[0], ox, fmaf(cp[1], oy, cp[2]));
+        float qy = fmaf(cp[3], ox, fmaf(cp[4], oy, cp[5]));
+        ox = qx; oy = qy;
+        cp = xf + 12;
+    }
+    const float csp = cp[1];
+    c = fmaf(c, 1.0f - csp, cp[0] * csp);
+    x = ox; y = oy;
+}
+
+// cuburn/code/iter.py:366-406: if the cell had reached 512 hits, swap it with zero and add its
+// unpacked contents (weighted by the hot-pixel multiplier) to the float accumulator.
+__device__ __forceinline__ void drain_if_full(bool ok, u64 old, uint32_t gi, float mult,
+                                              u64 *__restrict__ atom, float *__restrict__ out4, uint32_t &n_spill)
+{
+    if (ok && (uint32_t)(old >> 32) >= (256u << 23)) {
+        const u64 cur = __hip_atomic_exchange(atom + gi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(cur >> 32) != 0u) {
+            float yf, uf, vf, df;
+            unpack_cell(cur, yf, uf, vf, df);
+            const float m255 = mult * FL_INV255;
+            float *o = out4 + 4 * (size_t)gi;
+            __hip_atomic_fetch_add(o + 0, yf * m255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(o + 1, uf * m255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(o + 2, vf * m255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(o + 3, df * mult, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++n_spill;
+        }
+    }
+}
+
+__device__ __forceinline__ void reseed(float &x, float &y, float &c, mwc_t &r) {
+    x = mwc_next_11(r); y = mwc_next_11(r); c = mwc_next_01(r);
+}
+
+// counters: [0] accepted, [1] out of frame, [2] dropped by hot-pixel roulette, [3] spills
+template <int NW, bool COUNT>
+__global__ void __launch_bounds__(NW * 64)
+k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
+       const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points,
+       const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4,
+       u64 *__restrict__ counters, uint32_t astride, uint32_t aheight,
+       uint32_t round0, uint32_t nrounds, uint32_t fuse)
+{
+    constexpr int NT = NW * 64;
+    __shared__ float swp[2][3][NT];
+    __shared__ u64 palrow[FL_PAL_W];
+
+    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const uint32_t slot = blockIdx.x, ts = slot & (FL_NTEMPORAL - 1);
+    const int nxf = prog[1], has_final = prog[2], pstride = prog[3], cdf_off = prog[4];
+    const float *__restrict__ P = params + (size_t)ts * pstride;
+
+    for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
+
+    const size_t wi = (size_t)slot * NT + tid;
+    mwc_t rctx = {rng[wi].mul, rng[wi].state, rng[wi].carry};
+    float4 pt = points[wi];
+    float x = pt.x, y = pt.y, color = pt.z;
+
+    const float color_dither = 0.49f * mwc_next_11(rctx);                   // iter.py:185
+    if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);          // iter.py:209-216
+    __syncthreads();
+
+    uint32_t phase = round0 % 3u;
+    uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
+    bool pend_ok = false; uint32_t pend_gi = 0; float pend_mult = 1.0f; u64 pend_old = 0;
+
+    for (uint32_t rd = 0; rd < nrounds; ++rd) {
+        if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
+
+        // wave-coherent xform choice: lane 0's draw (iter.py:260-272 uses a shared cosel[])
+        const uint32_t sel = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
+        const float xfsel = (float)sel * (1.0f / 4294967296.0f);
+        int k = nxf - 1;
+        for (int i = nxf - 2; i >= 0; --i) if (xfsel <= P[cdf_off + i]) k = i;
+        apply_xf(prog, P, k, x, y, color, rctx);
+
+        // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
+        {
+            const uint32_t par = rd & 1u, dst = shuffle_dest<NW>(w, l, phase);
+            swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
+            __syncthreads();
+            x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+            phase = phase == 2 ? 0 : phase + 1;
+        }
+        if (rd < fuse) continue;                                            // iter.py:298-300
+
+        float fx = x, fy = y, fc = color;
+        if (has_final) apply_xf(prog, P, nxf, fx, fy, fc, rctx);            // iter.py:302-307
+        const float cx = fmaf(P[0], fx, fmaf(P[1], fy, P[2]));              // iter.py:306-309
+        const float cy = fmaf(P[3], fx, fmaf(P[4], fy, P[5]));
+        const uint32_t ix = trunca(cx), iy = trunca(cy);                    // iter.py:313
+        bool ok = ix < astride && iy < aheight;                             // iter.py:315-317
+        if (COUNT) n_oob += !ok;
+        const uint32_t gi = ok ? iy * astride + ix : 0u;
+
+        float mult = 1.0f;
+        if (ok) {                                                           // iter.py:319-329
+            const uint32_t flag = (hot[gi >> 4] >> ((gi & 15u) << 1)) & 3u;
+            if (flag) {
+                mult = hot_mult(flag);
+                if (mwc_next_01(rctx) > frcp(mult)) { ok = false; if (COUNT) ++n_drop; }
+            }
+        }
+        const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
+        const int ci = (int)__builtin_rintf(fminf(fmaxf(cf, 0.0f), 255.0f));
+        const u64 val = palrow[ci];                                         // iter.py:351
+
+        // Every add returns the previous cell value, but the value is only looked at one
+        // round later (pend_*), so its latency hides under the next round's work.  A cell seen
+        // at >= 512 hits is drained into the float accumulator before its 10-bit count can
+        // wrap.  (The reference checks 3 % of warp-rounds synchronously, iter.py:361-406; with
+        // wave-coherent hits that leaves a real chance of wrapping on concentrated flames.)
+        drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
+        pend_ok = ok; pend_gi = gi; pend_mult = mult;
+        if (ok) pend_old = __hip_atomic_fetch_add(atom + gi, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COUNT) n_acc += ok;
+    }
+
+    drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
+    points[wi] = make_float4(x, y, color, 0.0f);                            // iter.py:414-416
+    rng[wi].mul = rctx.mul; rng[wi].state = rctx.state; rng[wi].carry = rctx.carry;
+
+    if (COUNT) {
+        atomicAdd(counters + 0, (u64)n_acc);
+        atomicAdd(counters + 1, (u64)n_oob);
+        atomicAdd(counters + 2, (u64)n_drop);
+        atomicAdd(counters + 3, (u64)n_spill);
+    }
+}
+
+// Point-shuffle tap: one swap of the identity payload, for the bit-exact permutation test.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_shuffle_tap(uint32_t *out, uint32_t round)
+{
+    __shared__ uint32_t s[NW * 64];
+    const uint32_t tid = threadIdx.x;
+    s[shuffle_dest<NW>(tid >> 6, tid & 63, round % 3u)] = tid;
+    __syncthreads();
+    out[tid] = s[tid];
+}
+
+// cuburn/code/iter.py:420-544 flush_atom: drain packed cells into the float accumulator with
+// the hot-flag weight that was in force while they filled, zero them, and recompute the 2-bit
+// flags (16 pixels per u32 word at gi >> 4) from the accumulated density.
+__global__ void __launch_bounds__(256)
+k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__ hot, uint32_t nbins)
+{
+    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;      // nbins is a multiple of 512
+    if (gi >= nbins) return;
+    const uint32_t sh = (gi & 15u) << 1;
+    const uint32_t flag = (hot[gi >> 4] >> sh) & 3u;
+    const float mult = hot_mult(flag);
+    const u64 cell = __builtin_nontemporal_load(atom + gi);
+    __builtin_nontemporal_store(0ull, atom + gi);
+    float yf, uf, vf, df;
+    unpack_cell(cell, yf, uf, vf, df);
+    float4 o = out[gi];
+    const float m255 = mult * FL_INV255;
+    o.w = fmaf(df, mult, o.w);
+    o.x = fmaf(yf, m255, o.x);
+    o.y = fmaf(uf, m255, o.y);
+    o.z = fmaf(vf, m255, o.z);
+    out[gi] = o;
+    uint32_t nf = (uint32_t)(o.w > 128.0f) + (uint32_t)(o.w > 512.0f) + (uint32_t)(o.w > 2048.0f);
+    uint32_t word = nf << sh;
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    word |= __shfl_xor(word, 4);
+    word |= __shfl_xor(word, 8);
+    if ((gi & 15u) == 0) hot[gi >> 4] = word;
+}
+
+// ---- host-side launchers --------------------------------------------------------------------
+void launch_iter(hipStream_t st, int nw, bool count, uint32_t nslots,
+                 const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
+                 float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
+                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse)
+{
+#define LAUNCH(NW, C) hipLaunchKernelGGL((k_iter<NW, C>), dim3(nslots), dim3(NW * 64), 0, st, prog, params, palette, \
+        rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse)
+    if (nw == 4) { if (count) LAUNCH(4, true); else LAUNCH(4, false); }
+    else if (nw == 8) { if (count) LAUNCH(8, true); else LAUNCH(8, false); }
+#undef LAUNCH
+}
+
+void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins)
+{
+    hipLaunchKernelGGL(k_flush, dim3((nbins + 255) / 256), dim3(256), 0, st, atom, out, hot, nbins);
+}
+
+void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round)
+{
+    if (nw == 4) hipLaunchKernelGGL(k_shuffle_tap<4>, dim3(1), dim3(256), 0, st, out, round);
+    else hipLaunchKernelGGL(k_shuffle_tap<8>, dim3(1), dim3(512), 0, st, out, round);
+}

@@ -1,0 +1,41 @@
+// kernels.h — host-callable launchers of the gfx950 kernels (internal to libflame_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/flame_hip.h"
+
+typedef unsigned long long u64;
+
+// iter.hip
+void launch_iter(hipStream_t st, int nw, bool count, uint32_t nslots,
+                 const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
+                 float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
+                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse);
+void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins);
+void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
+
+// interp.hip
+void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes, const float4 *pals,
+                           float ts, float tstep, u64 *out);
+void launch_interp_params(hipStream_t st, float *params, const float *times, const float *knots,
+                          const int32_t *ops, uint32_t nops, uint32_t pstride, float ts, float tstep,
+                          fl_dim dim);
+
+// filters.hip
+void launch_yuv_to_rgb(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
+void launch_den_blur(hipStream_t st, fl_dim d, float *dst, const float4 *src, int pattern, int upsample, const float *coefs7);
+void launch_den_blur_1c(hipStream_t st, fl_dim d, float *dst, const float *src, int pattern, int upsample, const float *coefs7);
+void launch_full_blur(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, int pattern, int upsample, const float *coefs7);
+void launch_bilateral(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, const float *blur, int pattern,
+                      int radius, float sstd, float cstd, float dstd, float dpow, float gspeed);
+void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
+void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float highpow, float gam, float lin, float lingam);
+void launch_gamma_full_hi(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
+void launch_smearclip(hipStream_t st, fl_dim d, float4 *buf, const float4 *smear, float gam_m_1, float lin, float lingam);
+void launch_apply_gamma(hipStream_t st, fl_dim d, float *dst, const float4 *src, float gamma);
+void launch_haloclip(hipStream_t st, fl_dim d, float4 *buf, const float *den, float gam_m_1);
+void launch_plainclip(hipStream_t st, fl_dim d, float4 *buf, float gam_m_1, float lin, float lingam, float brightness);
+void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, float degamma);
+
+// output.hip
+void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);

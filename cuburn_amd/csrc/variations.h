@@ -1,0 +1,308 @@
+// variations.h — the flame variation functions, device side (gfx950).
+//
+// One wave applies ONE xform per round (wave-coherent selection), so the switch below is
+// a scalar branch: no lane divergence, and the record pointers `v` / `xf` are wave-uniform
+// (their loads become s_load).  Formulas: the flam3 variation set as used by
+// cuburn/code/variations.py:22-988 (flam3 numbering, cuburn/genome/variations.py:28-127).
+// v[0] = weight, v[1..] = genome parameters in sorted-name order then precalculated values
+// (include/flame_hip.h (5)); xf = owning xform record (pre affine xx,xy,xo,yx,yy,yo).
+#pragma once
+#include "flame_device.h"
+
+#define VW (v[0])
+#define VP(i) (v[1 + (i)])
+#define OUT(a, b) do { ox += (a); oy += (b); } while (0)
+
+__device__ __forceinline__ float v_atan2(float a, float b) { return atan2f(a, b); }
+// box-muller style radius used by gaussian_blur / radial_blur (variations.py:318-323)
+__device__ __forceinline__ float v_gauss_r(float w, mwc_t &r) {
+    return w * 0.57736f * fsqrt(fdiv(-2.0f * flog2(mwc_next_01(r)), FM_LOG2E));
+}
+
+// Returns false for an unknown id (host rejects such programs up front).
+__device__ __forceinline__ bool apply_variation(int id, const float *__restrict__ v,
+                                                const float *__restrict__ xf,
+                                                float &tx, float &ty, float &ox, float &oy, mwc_t &r)
+{
+    const float r2 = fmaf(tx, tx, ty * ty);
+    switch (id) {
+    case 0: OUT(tx * VW, ty * VW); break;                                              // linear
+    case 1: OUT(VW * fsin(tx), VW * fsin(ty)); break;                                  // sinusoidal
+    case 2: { float k = fdiv(VW, r2); OUT(tx * k, ty * k); } break;                    // spherical
+    case 3: { float s = fsin(r2), c = fcos(r2);                                        // swirl
+              OUT(VW * (s * tx - c * ty), VW * (c * tx + s * ty)); } break;
+    case 4: { float k = fdiv(VW, fsqrt(r2));                                           // horseshoe
+              OUT(k * (tx - ty) * (tx + ty), 2.0f * tx * ty * k); } break;
+    case 5: OUT(VW * v_atan2(tx, ty) * FM_1_PI, VW * (fsqrt(r2) - 1.0f)); break;       // polar
+    case 6: { float a = v_atan2(tx, ty), rr = fsqrt(r2);                               // handkerchief
+              OUT(VW * rr * fsin(a + rr), VW * rr * fcos(a - rr)); } break;
+    case 7: { float sq = fsqrt(r2), a = sq * v_atan2(tx, ty), rr = VW * sq;            // heart
+              OUT(rr * fsin(a), -rr * fcos(a)); } break;
+    case 8: { float a = VW * v_atan2(tx, ty) * FM_1_PI, rr = FM_PI * fsqrt(r2);        // disc
+              OUT(fsin(rr) * a, fcos(rr) * a); } break;
+    case 9: { float a = v_atan2(tx, ty), rr = fsqrt(r2), r1 = fdiv(VW, rr);            // spiral
+              OUT(r1 * (fcos(a) + fsin(rr)), r1 * (fsin(a) - fcos(rr))); } break;
+    case 10: { float a = v_atan2(tx, ty), rr = fsqrt(r2);                              // hyperbolic
+               OUT(fdiv(VW * fsin(a), rr), VW * fcos(a) * rr); } break;
+    case 11: { float a = v_atan2(tx, ty), rr = fsqrt(r2);                              // diamond
+               OUT(VW * fsin(a) * fcos(rr), VW * fcos(a) * fsin(rr)); } break;
+    case 12: { float a = v_atan2(tx, ty), rr = fsqrt(r2);                              // ex
+               float n0 = fsin(a + rr), n1 = fcos(a - rr);
+               float m0 = n0 * n0 * n0 * rr, m1 = n1 * n1 * n1 * rr;
+               OUT(VW * (m0 + m1), VW * (m0 - m1)); } break;
+    case 13: { float a = 0.5f * v_atan2(tx, ty);                                       // julia
+               if (mwc_next(r) & 1) a += FM_PI;
+               float rr = VW * fsqrt(fsqrt(r2));
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 14: { float nx = tx < 0.0f ? 2.0f : 1.0f, ny = ty < 0.0f ? 0.5f : 1.0f;      // bent
+               OUT(VW * nx * tx, VW * ny * ty); } break;
+    case 15: OUT(VW * (tx + xf[1] * fsin(ty * VP(0))),                                 // waves
+                 VW * (ty + xf[4] * fsin(tx * VP(1)))); break;
+    case 16: { float k = fdiv(2.0f * VW, fsqrt(r2) + 1.0f); OUT(k * ty, k * tx); } break;   // fisheye
+    case 17: { float dx = ftan(3.0f * ty), dy = ftan(3.0f * tx);                       // popcorn
+               OUT(VW * (tx + xf[2] * fsin(dx)), VW * (ty + xf[5] * fsin(dy))); } break;
+    case 18: { float dx = VW * fexp(tx - 1.0f);                                        // exponential
+               if (isfinite(dx)) { float dy = FM_PI * ty; OUT(dx * fcos(dy), dx * fsin(dy)); } } break;
+    case 19: { float a = v_atan2(tx, ty), sa = fsin(a), rr = VW * fpow(fsqrt(r2), sa); // power
+               OUT(rr * fcos(a), rr * sa); } break;
+    case 20: { float a = FM_PI * tx;                                                   // cosine
+               OUT(VW * fcos(a) * coshf(ty), -VW * fsin(a) * sinhf(ty)); } break;
+    case 21: { float dx = xf[2]; dx *= dx;                                             // rings
+               float rr = fsqrt(r2), a = v_atan2(tx, ty);
+               rr = VW * (fmodf(rr + dx, 2.0f * dx) - dx + rr * (1.0f - dx));
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 22: { float dx = xf[2]; dx *= dx * FM_PI;                                     // fan
+               float dx2 = 0.5f * dx, dy = xf[5], a = v_atan2(tx, ty);
+               a += (fmodf(a + dy, dx) > dx2) ? -dx2 : dx2;
+               float rr = VW * fsqrt(r2);
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 23: { float rr = fsqrt(r2), a = v_atan2(tx, ty), bd = 0.5f * (VP(0) - VP(1)); // blob: high low waves
+               rr *= VW * (VP(1) + bd * (1.0f + fsin(VP(2) * a)));
+               OUT(fsin(a) * rr, fcos(a) * rr); } break;
+    case 24: OUT(VW * (fsin(VP(0) * ty) - fcos(VP(1) * tx)),                           // pdj: a b c d
+                 VW * (fsin(VP(2) * tx) - fcos(VP(3) * ty))); break;
+    case 25: { float dy = VP(1), dx = VP(0); dx *= dx * FM_PI;                         // fan2: x y
+               float dx2 = 0.5f * dx, a = v_atan2(tx, ty), rr = VW * fsqrt(r2);
+               float t = a + dy - dx * truncf(fdiv(a + dy, dx));
+               a += (t > dx2) ? -dx2 : dx2;
+               OUT(rr * fsin(a), rr * fcos(a)); } break;
+    case 26: { float dx = VP(0); dx *= dx;                                             // rings2: val
+               float rr = fsqrt(r2), a = v_atan2(tx, ty);
+               rr += -2.0f * dx * (float)(int)fdiv(rr + dx, 2.0f * dx) + rr * (1.0f - dx);
+               OUT(VW * fsin(a) * rr, VW * fcos(a) * rr); } break;
+    case 27: { float k = fdiv(2.0f * VW, fsqrt(r2) + 1.0f); OUT(k * tx, k * ty); } break;   // eyefish
+    case 28: { float k = fdiv(VW, 0.25f * r2 + 1.0f); OUT(k * tx, k * ty); } break;    // bubble
+    case 29: OUT(VW * fsin(tx), VW * ty); break;                                       // cylinder
+    case 30: { float t = frcp(VP(2) - ty * VP(3));                                     // perspective: angle dist | mdist sin cos
+               OUT(VW * VP(2) * tx * t, VW * VP(4) * ty * t); } break;
+    case 31: { float a = mwc_next_01(r) * 2.0f * FM_PI, rr = VW * mwc_next_01(r);      // noise
+               OUT(tx * rr * fcos(a), ty * rr * fsin(a)); } break;
+    case 32: { float power = VP(1);                                                    // julian: dist power | cn
+               float t_rnd = truncf(mwc_next_01(r) * fabsf(power));
+               float a = fdiv(v_atan2(ty, tx) + 2.0f * FM_PI * t_rnd, power);
+               float rr = VW * fpow(r2, VP(2));
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 33: { float ang = v_atan2(ty, tx), power = VP(1);                             // juliascope
+               float t_rnd = truncf(mwc_next_01(r) * fabsf(power));
+               if (mwc_next(r) & 1) ang = -ang;
+               float a = fdiv(2.0f * FM_PI * t_rnd + ang, power);
+               float rr = VW * fpow(r2, VP(2));
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 34: { float a = mwc_next_01(r) * 2.0f * FM_PI, rr = VW * mwc_next_01(r);      // blur
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 35: { float a = mwc_next_01(r) * 2.0f * FM_PI, rr = v_gauss_r(VW, r);         // gaussian_blur
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 36: { float ba = VP(0) * FM_PI * 0.5f, spin = fsin(ba), zoom = fcos(ba);      // radial_blur: angle
+               float rr = v_gauss_r(VW, r), ra = fsqrt(r2);
+               float a = v_atan2(ty, tx) + spin * rr, rz = zoom * rr - 1.0f;
+               OUT(ra * fcos(a) + rz * tx, ra * fsin(a) + rz * ty); } break;
+    case 37: { float slices = VP(1);                                                   // pie: rotation slices thickness
+               float sl = truncf(mwc_next_01(r) * slices + 0.5f);
+               float a = VP(0) + fdiv(2.0f * FM_PI * (sl + mwc_next_01(r) * VP(2)), slices);
+               float rr = VW * mwc_next_01(r);
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 38: { float power = VP(2) * 0.5f, b = fdiv(2.0f * FM_PI, VP(3));              // ngon: circle corners power sides
+               float rf = fpow(r2, power), th = v_atan2(ty, tx);
+               float phi = th - b * floorf(fdiv(th, b));
+               if (phi > b * 0.5f) phi -= b;
+               float amp = fdiv(VP(1) * (frcp(fcos(phi)) - 1.0f) + VP(0), rf);
+               OUT(VW * tx * amp, VW * ty * amp); } break;
+    case 39: { float c1 = VP(0), c2 = VP(1);                                           // curl: c1 c2
+               float re = 1.0f + c1 * tx + c2 * (tx * tx - ty * ty), im = c1 * ty + 2.0f * c2 * tx * ty;
+               float k = fdiv(VW, re * re + im * im);
+               OUT(k * (tx * re + ty * im), k * (ty * re - tx * im)); } break;
+    case 40: { float rx = VP(0), ry = VP(1);                                           // rectangles: x y
+               OUT(VW * ((rx == 0.0f) ? tx : rx * (2.0f * floorf(fdiv(tx, rx)) + 1.0f) - tx),
+                   VW * ((ry == 0.0f) ? ty : ry * (2.0f * floorf(fdiv(ty, ry)) + 1.0f) - ty)); } break;
+    case 41: { float a = mwc_next_01(r) * VW * FM_PI, s = fsin(a);                     // arch
+               OUT(VW * s, fdiv(VW * s * s, fcos(a))); } break;
+    case 42: OUT(fdiv(VW * fsin(tx), fcos(ty)), VW * ftan(ty)); break;                 // tangent
+    case 43: { float a = mwc_next_01(r), b = mwc_next_01(r);                           // square
+               OUT(VW * (a - 0.5f), VW * (b - 0.5f)); } break;
+    case 44: { float a = VW * mwc_next_01(r) * FM_PI, k = fdiv(VW, r2);                // rays
+               float tr = VW * ftan(a) * k;
+               OUT(tr * fcos(tx), tr * fsin(ty)); } break;
+    case 45: { float rr = mwc_next_01(r) * VW * fsqrt(r2), s = fsin(rr), c = fcos(rr); // blade
+               OUT(VW * tx * (c + s), VW * tx * (c - s)); } break;
+    case 46: { float cr = fcos(VW * fsqrt(r2)), icr = frcp(cr);                        // secant2
+               icr += (cr < 0.0f ? 1.0f : -1.0f);
+               OUT(VW * tx, VW * icr); } break;
+    case 48: { float s = tx * tx - ty * ty, k = VW * fsqrt(frcp(s * s));               // cross
+               OUT(k * tx, k * ty); } break;
+    case 49: { float twist = VP(1), rotpi = VP(0) * FM_PI;                             // disc2: rot twist
+               float st = fsin(twist), ct = fcos(twist) - 1.0f;
+               if (twist > 2.0f * FM_PI) { float k = 1.0f + twist - 2.0f * FM_PI; st *= k; ct *= k; }
+               if (twist < -2.0f * FM_PI) { float k = 1.0f + twist + 2.0f * FM_PI; st *= k; ct *= k; }
+               float t = rotpi * (tx + ty), k = fdiv(VW * v_atan2(tx, ty), FM_PI);
+               OUT(k * (fsin(t) + ct), k * (fcos(t) + st)); } break;
+    case 50: { float th = 0.25f * (VP(1) * v_atan2(ty, tx) + FM_PI);                   // super_shape: holes m n1 n2 n3 rnd
+               float t1 = fpow(fabsf(fcos(th)), VP(3)), t2 = fpow(fabsf(fsin(th)), VP(4));
+               float rnd = VP(5), d = fsqrt(r2);
+               float k = fdiv(VW * ((rnd * mwc_next_01(r) + (1.0f - rnd) * d) - VP(0))
+                              * fpow(t1 + t2, fdiv(-1.0f, VP(2))), d);
+               OUT(k * tx, k * ty); } break;
+    case 51: { float k = fdiv(VW * (mwc_next_01(r) - VP(0)) * fcos(VP(1) * v_atan2(ty, tx)), fsqrt(r2));   // flower: holes petals
+               OUT(k * tx, k * ty); } break;
+    case 52: { float d = fsqrt(r2), ct = fdiv(tx, d);                                  // conic: eccentricity holes
+               float k = fdiv(fdiv(VW * (mwc_next_01(r) - VP(1)) * VP(0), 1.0f + VP(0) * ct), d);
+               OUT(k * tx, k * ty); } break;
+    case 53: { float rr = fsqrt(r2), sr = fsin(rr), cr = fcos(rr);                     // parabola: height width
+               float a = mwc_next_01(r), b = mwc_next_01(r);
+               OUT(VP(0) * VW * sr * sr * a, VP(1) * VW * cr * b); } break;
+    case 54: { float nx = tx < 0.0f ? VP(0) : 1.0f, ny = ty < 0.0f ? VP(1) : 1.0f;     // bent2: x y
+               OUT(VW * nx * tx, VW * ny * ty); } break;
+    case 55: { float t = r2 + 1.0f, x2 = tx * 2.0f, ps = -FM_PI_2 * VP(0);             // bipolar: shift
+               float y = 0.5f * v_atan2(2.0f * ty, r2 - 1.0f) + ps;
+               if (y > FM_PI_2) y = -FM_PI_2 + fmodf(y + FM_PI_2, FM_PI);
+               else if (y < -FM_PI_2) y = FM_PI_2 - fmodf(FM_PI_2 - y, FM_PI);
+               OUT(VW * 0.25f * FM_2_PI * flog(fdiv(t + x2, t - x2)), VW * FM_2_PI * y); } break;
+    case 56: { float rx = rintf(tx), ry = rintf(ty), fx = tx - rx, fy = ty - ry;       // boarders
+               if (mwc_next_01(r) > 0.75f) {
+                   OUT(VW * (fx * 0.5f + rx), VW * (fy * 0.5f + ry));
+               } else if (fabsf(fx) >= fabsf(fy)) {
+                   float s = fx >= 0.0f ? 0.25f : -0.25f;
+                   OUT(VW * (fx * 0.5f + rx + s), VW * (fy * 0.5f + ry + s * fdiv(fy, fx)));
+               } else {
+                   float s = fy >= 0.0f ? 0.25f : -0.25f;
+                   OUT(VW * (fx * 0.5f + rx + fdiv(fx, fy) * s), VW * (fy * 0.5f + ry + s));
+               } } break;
+    case 57: { float wx = VW * 1.3029400317411197908970256609023f, y2 = ty * 2.0f;     // butterfly
+               float k = wx * fsqrt(fdiv(fabsf(ty * tx), tx * tx + y2 * y2));
+               OUT(k * tx, k * y2); } break;
+    case 58: { float cs = VP(0), ics = frcp(cs);                                       // cell: size
+               float cx = floorf(tx * ics), cy = floorf(ty * ics);
+               float dx = tx - cx * cs, dy = ty - cy * cs;
+               cx = cx >= 0.0f ? cx * 2.0f : -(2.0f * cx + 1.0f);
+               cy = cy >= 0.0f ? cy * 2.0f : -(2.0f * cy + 1.0f);
+               OUT(VW * (dx + cx * cs), -VW * (dy + cy * cs)); } break;
+    case 59: { float a = v_atan2(ty, tx), lnr = 0.5f * flog(r2), power = frcp(VP(1));  // cpow: i power r
+               float va = 2.0f * FM_PI * power, vc = VP(2) * power, vd = VP(0) * power;
+               float ang = vc * a + vd * lnr + va * floorf(power * mwc_next_01(r));
+               float m = VW * fexp(vc * lnr - vd * a);
+               OUT(m * fcos(ang), m * fsin(ang)); } break;
+    case 60: OUT(VW * (tx + VP(0) * fexp(-ty * ty * VP(4))),                           // curve: xamp xlength yamp ylength | x2 y2
+                 VW * (ty + VP(2) * fexp(-tx * tx * VP(5)))); break;
+    case 61: { float tmp = r2 + 1.0f, tmp2 = 2.0f * tx;                                // edisc
+               float xmax = (fsqrt(tmp + tmp2) + fsqrt(tmp - tmp2)) * 0.5f;
+               float a1 = flog(xmax + fsqrt(xmax - 1.0f)), a2 = -acosf(fdiv(tx, xmax)), nw = fdiv(VW, 11.57034632f);
+               float snv = fsin(a1), csv = fcos(a1);
+               if (ty > 0.0f) snv = -snv;
+               OUT(nw * coshf(a2) * csv, nw * sinhf(a2) * snv); } break;
+    case 62: { float tmp = r2 + 1.0f, x2 = 2.0f * tx;                                  // elliptic
+               float xmax = 0.5f * (fsqrt(tmp + x2) + fsqrt(tmp - x2));
+               float a = fdiv(tx, xmax), b = 1.0f - a * a, ssx = xmax - 1.0f, nw = fdiv(VW, FM_PI_2);
+               b = b < 0.0f ? 0.0f : fsqrt(b);
+               ssx = ssx < 0.0f ? 0.0f : fsqrt(ssx);
+               float l = nw * flog(xmax + ssx);
+               OUT(nw * v_atan2(a, b), ty > 0.0f ? l : -l); } break;
+    case 63: { float a = v_atan2(ty, tx), lnr = 0.5f * flog(r2);                       // escher: beta
+               float vc = 0.5f * (1.0f + fcos(VP(0))), vd = 0.5f * fsin(VP(0));
+               float m = VW * fexp(vc * lnr - vd * a), n = vc * a + vd * lnr;
+               OUT(m * fcos(n), m * fsin(n)); } break;
+    case 64: { float ex = fexp(tx) * 0.5f, enx = fdiv(0.25f, ex), sn = fsin(ty), cn = fcos(ty);   // foci
+               float t = fdiv(VW, ex + enx - cn);
+               OUT(t * (ex - enx), t * sn); } break;
+    case 65: { float lx = VP(3), ly = VP(4), x = tx - lx, y = ty + ly, rr = fsqrt(x * x + y * y);  // lazysusan: space spin twist x y
+               if (rr < VW) {
+                   float a = v_atan2(y, x) + VP(1) + VP(2) * (VW - rr);
+                   OUT(VW * (rr * fcos(a) + lx), VW * (rr * fsin(a) - ly));
+               } else {
+                   rr = 1.0f + fdiv(VP(0), rr);
+                   OUT(VW * (rr * x + lx), VW * (rr * y - ly));
+               } } break;
+    case 66: { float w2 = VW * VW;                                                     // loonie
+               float k = (r2 < w2) ? VW * fsqrt(fdiv(w2, r2) - 1.0f) : VW;
+               OUT(k * tx, k * ty); } break;
+    case 67: { float g = mwc_next_01(r); g += mwc_next_01(r); g += mwc_next_01(r); g += mwc_next_01(r);   // pre_blur
+               g = VW * (g - 2.0f);
+               float a = mwc_next_01(r) * 2.0f * FM_PI;
+               tx += g * fcos(a); ty += g * fsin(a); } break;
+    case 68: { float mx = VP(0), my = VP(1), xr = 2.0f * mx, yr = 2.0f * my;           // modulus: x y
+               float ax = (tx > mx) ? VW * (-mx + fmodf(tx + mx, xr)) : (tx < -mx) ? VW * (mx - fmodf(mx - tx, xr)) : VW * tx;
+               float ay = (ty > my) ? VW * (-my + fmodf(ty + my, yr)) : (ty < -my) ? VW * (my - fmodf(my - ty, yr)) : VW * ty;
+               OUT(ax, ay); } break;
+    case 69: { float tpf = 2.0f * FM_PI * VP(2);                                       // oscope: amplitude damping frequency separation
+               float t = VP(0) * fexp(-fabsf(tx) * VP(1)) * fcos(tpf * tx) + VP(3);
+               OUT(VW * tx, (fabsf(ty) <= t) ? -VW * ty : VW * ty); } break;
+    case 70: { float p2v = fdiv(VW, FM_PI);                                            // polar2
+               OUT(p2v * v_atan2(tx, ty), 0.5f * p2v * flog(r2)); } break;
+    case 71: OUT(VW * (tx + VP(1) * fsin(ftan(ty * VP(0)))),                           // popcorn2: c x y
+                 VW * (ty + VP(2) * fsin(ftan(tx * VP(0))))); break;
+    case 72: { float k = frcp(fsqrt(r2) * (r2 + frcp(VW))); OUT(tx * k, ty * k); } break;   // scry
+    case 73: { float sx2 = VP(0) * VP(0), sy2 = VP(2) * VP(2);                         // separation: x xinside y yinside
+               float ax = tx > 0.0f ? VW * (fsqrt(tx * tx + sx2) - tx * VP(1)) : -VW * (fsqrt(tx * tx + sx2) + tx * VP(1));
+               float ay = ty > 0.0f ? VW * (fsqrt(ty * ty + sy2) - ty * VP(3)) : -VW * (fsqrt(ty * ty + sy2) + ty * VP(3));
+               OUT(ax, ay); } break;
+    case 74: OUT((fcos(ty * VP(1) * FM_PI) >= 0.0f) ? VW * tx : -VW * tx,              // split: xsize ysize
+                 (fcos(tx * VP(0) * FM_PI) >= 0.0f) ? VW * ty : -VW * ty); break;
+    case 75: OUT(VW * (tx + copysignf(VP(0), tx)), VW * (ty + copysignf(VP(1), ty))); break;   // splits: x y
+    case 76: { float rx = floorf(tx + 0.5f), fx = tx - rx;                             // stripes: space warp
+               OUT(VW * (fx * (1.0f - VP(0)) + rx), VW * (ty + fx * fx * VP(1))); } break;
+    case 77: { float rr = fsqrt(r2), a = v_atan2(ty, tx) + VP(3) * rr, wc = VP(1), wa = VP(0);   // wedge: angle count hole swirl
+               float c = floorf((wc * a + FM_PI) * FM_1_PI * 0.5f);
+               a = a * (1.0f - wa * wc * FM_1_PI * 0.5f) + c * wa;
+               rr = VW * (rr + VP(2));
+               OUT(rr * fcos(a), rr * fsin(a)); } break;
+    case 80: { float rr = fsqrt(r2), a = v_atan2(ty, tx);                              // whorl: inside outside
+               a += fdiv(rr < VW ? VP(0) : VP(1), VW - rr);
+               OUT(VW * rr * fcos(a), VW * rr * fsin(a)); } break;
+    case 81: OUT(VW * (tx + VP(2) * fsin(ty * VP(0))), VW * (ty + VP(3) * fsin(tx * VP(1)))); break;   // waves2: freqx freqy scalex scaley
+    case 82: { float e = fexp(tx); OUT(VW * e * fcos(ty), VW * e * fsin(ty)); } break;  // exp
+    case 83: OUT(VW * 0.5f * flog(r2), VW * v_atan2(ty, tx)); break;                   // log
+    case 84: OUT(VW * fsin(tx) * coshf(ty), VW * fcos(tx) * sinhf(ty)); break;         // sin
+    case 85: OUT(VW * fcos(tx) * coshf(ty), -VW * fsin(tx) * sinhf(ty)); break;        // cos
+    case 86: { float d = frcp(fcos(2.0f * tx) + coshf(2.0f * ty));                     // tan
+               OUT(VW * d * fsin(2.0f * tx), VW * d * sinhf(2.0f * ty)); } break;
+    case 87: { float d = fdiv(2.0f, fcos(2.0f * tx) + coshf(2.0f * ty));               // sec
+               OUT(VW * d * fcos(tx) * coshf(ty), VW * d * fsin(tx) * sinhf(ty)); } break;
+    case 88: { float d = fdiv(2.0f, coshf(2.0f * ty) - fcos(2.0f * tx));               // csc
+               OUT(VW * d * fsin(tx) * coshf(ty), -VW * d * fcos(tx) * sinhf(ty)); } break;
+    case 89: { float d = frcp(coshf(2.0f * ty) - fcos(2.0f * tx));                     // cot
+               OUT(VW * d * fsin(2.0f * tx), -VW * d * sinhf(2.0f * ty)); } break;
+    case 90: OUT(VW * sinhf(tx) * fcos(ty), VW * coshf(tx) * fsin(ty)); break;         // sinh
+    case 91: OUT(VW * coshf(tx) * fcos(ty), VW * sinhf(tx) * fsin(ty)); break;         // cosh
+    case 92: { float d = frcp(fcos(2.0f * ty) + coshf(2.0f * tx));                     // tanh
+               OUT(VW * d * sinhf(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
+    case 93: { float d = fdiv(2.0f, fcos(2.0f * ty) + coshf(2.0f * tx));               // sech
+               OUT(VW * d * fcos(ty) * coshf(tx), -VW * d * fsin(ty) * sinhf(tx)); } break;
+    case 94: { float d = fdiv(2.0f, coshf(2.0f * tx) - fcos(2.0f * ty));               // csch
+               OUT(VW * d * sinhf(tx) * fcos(ty), -VW * d * coshf(tx) * fsin(ty)); } break;
+    case 95: { float d = frcp(coshf(2.0f * tx) - fcos(2.0f * ty));                     // coth
+               OUT(VW * d * sinhf(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
+    case 97: { float xpw = tx + VW, xmw = tx - VW, y2 = ty * ty;                       // flux: spread
+               float ar = VW * (2.0f + VP(0)) * fsqrt(fdiv(fsqrt(y2 + xpw * xpw), fsqrt(y2 + xmw * xmw)));
+               float aa = (v_atan2(ty, xmw) - v_atan2(ty, xpw)) * 0.5f;
+               OUT(ar * fcos(aa), ar * fsin(aa)); } break;
+    case 98: { float ima = VP(0), imb = VP(1), imc = VP(2), imd = VP(3);               // mobius: im_a..im_d re_a..re_d
+               float rea = VP(4), reb = VP(5), rec = VP(6), red = VP(7);
+               float re_u = rea * tx - ima * ty + reb, im_u = rea * ty + ima * tx + imb;
+               float re_v = rec * tx - imc * ty + red, im_v = rec * ty + imc * tx + imd;
+               float k = fdiv(VW, re_v * re_v + im_v * im_v);
+               OUT(k * (re_u * re_v + im_u * im_v), k * (im_u * re_v - re_u * im_v)); } break;
+    default: return false;
+    }
+    return true;
+}
+#undef VW
+#undef VP
+#undef OUT

@@ -1,0 +1,191 @@
+"""
+Resources and tools to perform rendering — the drop-in for cuburn.render.
+
+Same entry points as cuburn/render.py:23-434: ``Dimensions``, ``Framebuffers.calc_dim``,
+``Renderer(gnm, gprof)``, ``RenderManager().queue_frame(rdr, gnm, gprof, tc)`` returning
+``(evt, h_out)`` with ``evt.synchronize() / .query() / .time()``.  All device work happens
+in libflame_hip.so through the C ABI of include/flame_hip.h.
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib, filters, output, mwc
+from .packer import GenomePacker
+from .genome.util import palette_decode
+
+RenderedImage = namedtuple('RenderedImage', 'buf idx gpu_time')
+Dimensions = namedtuple('Dimensions', 'w h aw ah astride')
+
+
+class DurationEvent(object):
+    """Completion handle of one queued frame (cuburn/render.py:26-38)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._ms = None
+
+    def synchronize(self):
+        if self._ms is None:
+            ms = C.c_float()
+            _lib.check(_lib.load().fl_frame_ms(self._ctx, C.byref(ms)))
+            self._ms = ms.value
+        return self
+
+    def query(self):
+        self.synchronize()
+        return True
+
+    def time(self):
+        """Milliseconds from the start of the frame to the end of its D2H copy."""
+        return self.synchronize()._ms
+
+
+class Framebuffers(object):
+    """
+    The accumulation / filter buffers and the stream that serialises their use
+    (cuburn/render.py:40-170).  Device memory is owned by the native context.
+    """
+    gutter = 12
+
+    @classmethod
+    def calc_dim(cls, width, height):
+        """Padded dimensions: gutter 12, (awidth % 32) == 0 after striding, (aheight % 16) == 0."""
+        awidth = width + 2 * cls.gutter
+        aheight = 16 * int(np.ceil((height + 2 * cls.gutter) / 16.))
+        astride = 32 * int(np.ceil(awidth / 32.))
+        return Dimensions(width, height, awidth, aheight, astride)
+
+    def __init__(self, device=0, nslots=1024, host_seed=None, stream=None):
+        lib = _lib.load()
+        self.nslots = nslots
+        self.nwalkers = (nslots + 64) * 256
+        seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, host_seed))
+        ctx = C.c_void_p()
+        _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, nslots, C.byref(ctx)))
+        self.ctx = ctx
+        self._host = {}
+
+    def host_buffer(self, shape, dtype):
+        key = (tuple(shape), dtype)
+        if key not in self._host:
+            self._host[key] = [np.empty(shape, dtype), np.empty(shape, dtype)]
+        pair = self._host[key]
+        pair.reverse()                      # at most two frames in flight (render.py:432-433)
+        return pair[0]
+
+    def set_dim(self, width, height, stream=None):
+        return self.calc_dim(width, height)
+
+    def read(self, which, shape, dtype, genome=None):
+        """Debug tap: copy a device buffer to the host."""
+        arr = np.empty(shape, dtype)
+        _lib.check(_lib.load().fl_read_buffer(self.ctx, genome, _lib.BUF[which], arr.ctypes.data, arr.nbytes))
+        return arr
+
+    def write(self, which, arr, genome=None):
+        arr = np.ascontiguousarray(arr)
+        _lib.check(_lib.load().fl_write_buffer(self.ctx, genome, _lib.BUF[which], arr.ctypes.data, arr.nbytes))
+
+    def free(self):
+        if self.ctx:
+            _lib.load().fl_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Renderer(object):
+    """
+    A genome prepared for rendering: packer layout + device program + filters + output
+    (cuburn/render.py:225-251).  ``compile`` here builds the xform program instead of CUDA.
+    """
+
+    @classmethod
+    def compile(cls, gnm, arch=None, keep=False):
+        packer = GenomePacker(gnm)
+        return packer, packer.prog, packer.ops_array
+
+    def __init__(self, gnm, gprof, keep=False, arch=None):
+        self.packer, self.lib, self.cubin = self.compile(gnm, keep=keep, arch=arch)
+        self.mod = None          # device handle, created on first use by a RenderManager
+        self.filts = filters.create(gprof)
+        self.out = output.get_output_for_profile(gprof)
+
+    def _handle(self, fb):
+        if self.mod is None:
+            g = C.c_void_p()
+            prog = np.ascontiguousarray(self.packer.prog)
+            ops = np.ascontiguousarray(self.packer.ops_array)
+            _lib.check(_lib.load().fl_genome_create(fb.ctx, prog.ctypes.data, len(prog), ops.ctypes.data,
+                                                    len(ops), self.packer.nrows, C.byref(g)))
+            self.mod = g
+        return self.mod
+
+    def __del__(self):
+        try:
+            if self.mod:
+                _lib.load().fl_genome_destroy(self.mod)
+        except Exception:
+            pass
+
+
+class RenderManager(object):
+    """Frame queue (cuburn/render.py:253-434)."""
+
+    accum_mode = _lib.ACCUM_ATOMIC
+    fuse = 256                      # write-disabled iterations per walker per frame (render.py:215)
+
+    def __init__(self, device=None, nslots=1024, host_seed=None, stream=None):
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', 0)) if 'LOCAL_RANK' in os.environ else 0
+        self.fb = Framebuffers(device, nslots, host_seed, stream)
+        self.last_nsamples = 0
+
+    def _copy(self, rdr, gnm):
+        """Upload packed splines and palettes (cuburn/render.py:264-285)."""
+        times, knots = rdr.packer.pack(gnm)
+        palsrc = dict([(v[0], palette_decode(v[1:])) for v in gnm['palette']])
+        ptimes, pvals = zip(*sorted(palsrc.items()))
+        palettes = np.ascontiguousarray(np.array(pvals, dtype=np.float32))
+        palette_times = np.full(32, 1e9, dtype=np.float32)
+        palette_times[:len(ptimes)] = ptimes
+        _lib.check(_lib.load().fl_genome_upload(self.fb.ctx, rdr._handle(self.fb), times.ctypes.data,
+                                                knots.ctypes.data, palettes.ctypes.data,
+                                                palette_times.ctypes.data, len(ptimes)))
+
+    def queue_frame(self, rdr, gnm, gprof, tc, copy=True):
+        """
+        Queue one frame at centre time ``tc``; returns ``(evt, h_out)`` (render.py:374-434).
+        """
+        lib = _lib.load()
+        dim = self.fb.set_dim(gprof.width, gprof.height)
+        td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
+        ts = tc - 0.5 * td
+        g = rdr._handle(self.fb)
+        if copy:
+            self._copy(rdr, gnm)
+        _lib.check(lib.fl_interp(self.fb.ctx, g, dim.w, dim.h, ts, td))
+        nsamps = gprof.spp(tc) * dim.w * dim.h
+        run = C.c_uint64()
+        _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse, self.accum_mode,
+                                  C.byref(run)))
+        self.last_nsamples = run.value
+        for filt in rdr.filts:
+            params = getattr(gprof.filters, filt.name)
+            filt.apply(self.fb, gprof, params, dim, tc)
+        rdr.out.convert(self.fb, gprof, dim)
+        h_out = rdr.out.copy(self.fb, dim)
+        return DurationEvent(self.fb.ctx), h_out
+
+    def timings(self):
+        """HIP-event times (ms) of the last frame's iterate, flush and filter kernels."""
+        it, fl, ft, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
+        _lib.check(_lib.load().fl_timings(self.fb.ctx, C.byref(it), C.byref(fl), C.byref(ft), C.byref(n)))
+        return dict(iter_ms=it.value, flush_ms=fl.value, filter_ms=ft.value, launches=n.value)

@@ -1,0 +1,226 @@
+/*
+ * flame_hip.h — C ABI of the MI355X-native fractal-flame hot path (libflame_hip.so).
+ *
+ * Drop-in boundary for cuburn's device path.  Each entry point cites the reference
+ * interface (file:line in stevenrobertson/cuburn) it replaces.  Plain C types only:
+ * no C++ / torch / HIP types cross this boundary (streams and device pointers travel
+ * as void* / uint64_t).
+ *
+ * Status codes: 0 = ok; negative = error (FL_E_*); fl_last_error() gives text.
+ * Threading: one fl_ctx per GPU per thread; calls on one ctx are not re-entrant
+ * (cuburn/render.py:401-402 makes the same statement for RenderManager).
+ */
+#ifndef FLAME_HIP_H
+#define FLAME_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_ABI_VERSION 1
+
+enum {
+    FL_OK = 0,
+    FL_E_INVAL = -1,      /* bad argument / malformed program                      */
+    FL_E_NOMEM = -2,      /* hipErrorOutOfMemory; ctx stays usable (render.py:140-147) */
+    FL_E_HIP = -3,        /* any other HIP runtime error                            */
+    FL_E_NODEV = -4,      /* no usable gfx950 device                                */
+    FL_E_UNSUPPORTED = -5 /* variation id / filter id not implemented               */
+};
+
+/* ------------------------------------------------------------------------------------
+ * Formats that cross the boundary
+ * ------------------------------------------------------------------------------------
+ *
+ * (1) Dimensions — cuburn/render.py:79-89 (Framebuffers.calc_dim): gutter 12,
+ *     aw = w + 24, astride = ceil32(aw), ah = ceil16(h + 24).
+ */
+typedef struct fl_dim {
+    uint32_t w, h, aw, ah, astride;
+} fl_dim;
+
+/* (2) MWC RNG state — cuburn/code/mwc.py:49-55 (mwc_st), 3 x u32, array-of-structs. */
+typedef struct fl_mwc {
+    uint32_t mul, state, carry;
+} fl_mwc;
+
+/* (3) Packed accumulator cell — cuburn/code/interp.py:428-429 (writer),
+ *     cuburn/code/iter.py:385-389,464-468 (reader).  64-bit cell:
+ *        hi[31:22] count (10 b) | hi[21:4] sum Y (18 b) | {hi[3:0],lo[31:18]} sum U (18 b)
+ *        | lo[17:0] sum V (18 b)
+ *     A palette entry is pre-packed as hi = (1<<22)|(y<<4), lo = (u<<18)|v, y,u,v in 0..255.
+ *
+ * (4) Spline rows — cuburn/code/interp.py:207-232 (GenomePacker.pack): per genome
+ *     parameter one row of FL_KNOTS (=32) knot times (padded 1e9) and FL_KNOTS knot
+ *     values; normalisation per cuburn/genome/use.py:129-158.
+ */
+#define FL_KNOTS 32
+#define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples */
+#define FL_PAL_W 256        /* cuburn/render.py:201-202 palette surface 256 x 64 */
+#define FL_PAL_H 64
+#define FL_GUTTER 12        /* cuburn/render.py:77 */
+
+/* (5) Xform program (int32 words) — replaces the per-genome generated CUDA of
+ *     cuburn/code/iter.py:121-149,559-575 with a data description interpreted by one
+ *     precompiled kernel.  All offsets are in 32-bit words.
+ *
+ *       prog[0]  FL_PROG_MAGIC
+ *       prog[1]  nxf        number of selectable xforms (string-sorted key order,
+ *                            cuburn/genome/use.py:88-91)
+ *       prog[2]  has_final  0/1 (cuburn/code/iter.py:303-307)
+ *       prog[3]  pstride    floats per temporal-sample parameter block
+ *       prog[4]  cdf_off    block offset of CDF[nxf] (cuburn/code/iter.py:12-30; entry
+ *                            nxf-1 is stored too and is >= 1)
+ *       prog[5..7] reserved (0)
+ *       prog[8+i] i in [0, nxf+has_final): word offset in prog of xform descriptor i
+ *                            (the final xform, if any, is descriptor nxf)
+ *     xform descriptor:
+ *       d[0] poff    block offset of the xform float record
+ *       d[1] xflags  bit0: has post affine
+ *       d[2] nvar    number of variations (sorted-name order, cuburn/code/iter.py:132)
+ *       d[3+2j] variation id (flam3 numbering, cuburn/genome/variations.py:28-127)
+ *       d[4+2j] voff: block offset of variation record {weight, params...}
+ *     xform float record at poff:
+ *       pre affine xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:81-95) ; if bit0: post affine
+ *       (same six) ; color ; color_speed
+ *     parameter block, floats [0..5]: camera xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:56-79)
+ *     variation record: weight, then the variation's genome parameters in sorted-name
+ *       order, then its precalculated values (see fl_var_info).
+ */
+#define FL_PROG_MAGIC 0x464c5031 /* 'FLP1' */
+#define FL_PROG_HDR 8
+#define FL_MAX_XFORMS 64
+#define FL_MAX_PSTRIDE 1024 /* cuburn/render.py:185 max_params */
+
+/* (6) Interpolation op list (int32 x 4 per op) — replaces the generated
+ *     interp_iter_params kernel body (cuburn/code/interp.py:234-272) and the precalc
+ *     snippets registered through PrecalcWrapper._code.  op = {kind, dst, a, b}:
+ */
+enum {
+    FL_OP_SPLINE = 0,     /* dst <- catmull_rom(row a)        (interp.py:318-355)        */
+    FL_OP_SPLINE_MAG = 1, /* dst <- catmull_rom_mag(row a)    (interp.py:299-316,339-353)*/
+    FL_OP_CAMERA = 2,     /* dst[0..5] <- camera precalc; rows a..a+3 = rotation,
+                             center.x, center.y, scale(mag)   (iter.py:56-79)            */
+    FL_OP_AFFINE = 3,     /* dst[0..5] <- affine precalc; rows a..a+5 = angle, spread,
+                             magnitude.x(mag), magnitude.y(mag), offset.x, offset.y
+                             (iter.py:81-95)                                             */
+    FL_OP_CDF = 4,        /* dst[0..b-1] <- cumulative density; rows a..a+b-1 = xform
+                             weights (iter.py:12-30)                                     */
+    FL_OP_RATIO2 = 5,     /* dst <- row a / (2 * row b)   julian/juliascope cn
+                             (variations.py:292-294); a = dist(mag), b = power(mag)      */
+    FL_OP_INVSQ = 6,      /* dst <- 1/(v*v + 1e-20), v = row a  (waves, variations.py:136-140) */
+    FL_OP_PERSP = 7,      /* dst[0..2] <- mdist, sin, cos; row a = angle, row b = dist(mag)
+                             (variations.py:267-273)                                     */
+    FL_OP_INVSQ_MAX = 8   /* dst <- 1/max(1e-20, v*v), v = row a (mag)  (curve, variations.py:630-634) */
+};
+
+/* ------------------------------------------------------------------------------------
+ * Entry points
+ * ------------------------------------------------------------------------------------ */
+
+typedef struct fl_ctx fl_ctx;       /* RenderManager + Framebuffers state (render.py:40-170,253-262) */
+typedef struct fl_genome fl_genome; /* Renderer's compiled module + packer layout (render.py:225-251) */
+
+int fl_abi_version(void);
+const char *fl_last_error(void);
+
+/* cuburn/render.py:79-89 Framebuffers.calc_dim */
+void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
+
+/* cuburn/render.py:253-262 RenderManager.__init__ + :91-104 Framebuffers.__init__:
+ * device, streams, walker/RNG state (persistent across frames, render.py:95-104).
+ * `seeds` = nwalkers x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
+ * nwalkers must be (nslots + FL_PAL_H) * 256.  stream = hipStream_t or NULL. */
+int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nslots, fl_ctx **out);
+void fl_ctx_destroy(fl_ctx *ctx);
+int fl_ctx_sync(fl_ctx *ctx);
+
+/* cuburn/render.py:232-251 Renderer.compile/load: takes the xform program (5) and the
+ * interpolation op list (6) instead of generated source. */
+int fl_genome_create(fl_ctx *ctx, const int32_t *prog, uint32_t nprog,
+                     const int32_t *ops, uint32_t nops, uint32_t nrows, fl_genome **out);
+void fl_genome_destroy(fl_genome *g);
+
+/* cuburn/render.py:264-285 RenderManager._copy: upload packed splines and palettes.
+ * times/knots: nrows x FL_KNOTS floats; pal_rgba: npal x 256 x 4 floats;
+ * pal_times: FL_KNOTS floats padded 1e9. */
+int fl_genome_upload(fl_ctx *ctx, fl_genome *g, const float *times, const float *knots,
+                     const float *pal_rgba, const float *pal_times, uint32_t npal);
+
+/* cuburn/render.py:289-307 RenderManager._interp: interp_palette_flat + interp_iter_params
+ * for the frame window [ts, ts+td). */
+int fl_interp(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, float ts, float td);
+
+/* Accumulation back-ends for fl_iterate. */
+enum {
+    FL_ACCUM_ATOMIC = 0, /* 64-bit packed global atomics, as cuburn/code/iter.py:331-411 */
+    FL_ACCUM_BINNED = 1  /* LDS-staged tile binning, then packed adds per tile          */
+};
+
+/* cuburn/render.py:316-372 RenderManager._iter: clears, fuse, iteration rounds, flushes.
+ * nsamples = write-enabled chaos-game iterations requested (spp*w*h, render.py:331);
+ * the count actually run (rounded up to whole launches) is returned in *nsamples_run.
+ * fuse = write-disabled iterations per walker at frame start (reference: 256). */
+int fl_iterate(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
+               uint32_t fuse, int accum_mode, uint64_t *nsamples_run);
+
+/* cuburn/filters.py:45-53,56-95,98-108,138-174 Filter.apply — one call per filter, result
+ * left in the front buffer (filters.py:29-35).  params are the host-derived scalars. */
+enum {
+    FL_FILT_YUV = 0,       /* yuv_to_rgb       code/filters.py:71-77   params: none                 */
+    FL_FILT_BILATERAL = 1, /* DE chain         filters.py:62-95        sstd,cstd,dstd,dpow,gspeed   */
+    FL_FILT_LOGSCALE = 2,  /* logscale         code/filters.py:41-53   k1,k2                        */
+    FL_FILT_COLORCLIP = 3, /* colorclip        code/filters.py:354-412 vib,highpow,gam,lin,lingam   */
+    FL_FILT_SMEARCLIP = 4, /* smearclip chain  filters.py:142-163      width,gam_m_1,lin,lingam     */
+    FL_FILT_HALOCLIP = 5,  /* haloclip chain   filters.py:113-130      gam_m_1                      */
+    FL_FILT_PLAINCLIP = 6, /* plainclip        code/filters.py:332-350 gam_m_1,lin,lingam,brightness*/
+    FL_FILT_LOGENCODE = 7  /* logencode        code/filters.py:81-90   degamma                      */
+};
+int fl_filter(fl_ctx *ctx, int filter_id, uint32_t w, uint32_t h, const float *params, uint32_t nparams);
+
+/* cuburn/output.py:83-88,120-125 (convert+copy): f32 -> rgba8 / rgba16 with dither
+ * (cuburn/code/output.py:7-71), gutter cropped; async D2H into host_out (or device copy
+ * when dev_out != 0). fmt: 0 = u8 x4, 1 = u16 x4. */
+int fl_output(fl_ctx *ctx, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out);
+
+/* cuburn/render.py:26-38 DurationEvent: ms from the start of the current frame
+ * (first fl_interp) to the last queued op; blocks until done. */
+int fl_frame_ms(fl_ctx *ctx, float *ms);
+
+/* ---- measurement taps (bench.py / tests only) ---- */
+/* HIP-event time of the iterate+flush kernels and of the filter kernels of the last frame. */
+int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *niter_launches);
+
+/* ---- debug taps (tests only): read/write device state ---- */
+enum {
+    FL_BUF_FRONT = 0,   /* float4[nbins]  accumulator / filter result (render.py:44-48)  */
+    FL_BUF_BACK = 1,    /* float4[nbins]                                                   */
+    FL_BUF_PARAMS = 2,  /* float[FL_NTEMPORAL * pstride] interpolated parameter blocks     */
+    FL_BUF_PALETTE = 3, /* u64[FL_PAL_H * FL_PAL_W] packed palette (interp.py:409-433)     */
+    FL_BUF_POINTS = 4,  /* float4[nwalkers] walker points (render.py:102-104)              */
+    FL_BUF_SEEDS = 5,   /* fl_mwc[nwalkers]                                                */
+    FL_BUF_ATOM = 6,    /* u64[nbins] packed integer accumulator of the current side      */
+    FL_BUF_HOT = 7,     /* u32[nbins/16] hot-pixel flags of the current side               */
+    FL_BUF_SIDE = 8     /* float4[nbins] side buffer                                       */
+};
+int fl_read_buffer(fl_ctx *ctx, fl_genome *g, int which, void *host_dst, size_t nbytes);
+int fl_write_buffer(fl_ctx *ctx, fl_genome *g, int which, const void *host_src, size_t nbytes);
+
+/* Single-launch taps for bit-exact tests: run `nrounds` rounds (first `fuse` write-disabled)
+ * for every slot with the given global round counter, no clears, no flush. */
+int fl_debug_iter_launch(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, uint32_t round0,
+                         uint32_t nrounds, uint32_t fuse, int accum_mode);
+int fl_debug_flush(fl_ctx *ctx, uint32_t w, uint32_t h);
+int fl_debug_clear(fl_ctx *ctx, uint32_t w, uint32_t h, int reset_points);
+/* Point-shuffle tap: out[dst_thread] = src_thread after one swap with round counter `round`. */
+int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
+/* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
+int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAME_HIP_H */
