@@ -799,9 +799,10 @@ void ref_flush(const ref_dim *dim, uint64_t *atom, float *out4, uint32_t *hot)
 }
 
 /* ------------------------------------------------------------------ flam3-style baseline */
-typedef struct {
+typedef struct f3_job {
     const ref_dim *dim; const int32_t *prog; const float *params; const float *palf;
     ref_mwc rng; uint64_t nsamples; int fuse; float *hist; uint64_t accepted; int tid; int nthreads;
+    struct f3_job *all; pthread_barrier_t *bar; float *out4;
 } f3_job;
 
 static void *f3_worker(void *arg)
@@ -809,11 +810,13 @@ static void *f3_worker(void *arg)
     f3_job *j = arg;
     const int32_t *prog = j->prog;
     int pstride = prog[3], nxf = prog[1], has_final = prog[2];
+    const uint32_t astride = j->dim->astride, ah = j->dim->ah;
+    const size_t nfl = (size_t)ah * astride * 4;
+    j->hist = calloc(nfl, sizeof(float));          /* first touch on the worker's own NUMA node */
     ref_mwc *r = &j->rng;
     float x = ref_mwc_next_11(r), y = ref_mwc_next_11(r), c = ref_mwc_next_01(r);
     int fuse = j->fuse;
     uint64_t done = 0, chunk = 0;
-    const uint32_t astride = j->dim->astride, ah = j->dim->ah;
     while (done < j->nsamples) {
         /* one temporal sample per 4096-iteration chunk, interleaved across threads */
         uint32_t ts = (uint32_t)((chunk * j->nthreads + j->tid) & 1023);
@@ -841,17 +844,25 @@ static void *f3_worker(void *arg)
         done += n;
         chunk++;
     }
+    /* merge: every worker sums one stripe of the image over all private histograms */
+    pthread_barrier_wait(j->bar);
+    size_t lo = nfl * (size_t)j->tid / j->nthreads, hi = nfl * (size_t)(j->tid + 1) / j->nthreads;
+    for (int t = 0; t < j->nthreads; ++t) {
+        const float *h = j->all[t].hist;
+        for (size_t i = lo; i < hi; ++i) j->out4[i] += h[i];
+    }
+    pthread_barrier_wait(j->bar);
+    free(j->hist);
     return NULL;
 }
 
 /* Classic flam3-style chaos game: every walker draws its own xform each iteration
- * (no wave coherence, no point swap), private float histogram per thread, merged at the
- * end.  Returns the wall seconds of iterate + merge.  out4 is ADDED to. */
+ * (no wave coherence, no point swap), one private float histogram per thread (allocated and
+ * merged in parallel).  Returns the wall seconds of iterate + merge.  out4 is ADDED to. */
 double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *params,
                         const uint64_t *palette, const ref_mwc *seeds, uint32_t nseeds,
                         uint64_t nsamples, int nthreads, int fuse, float *out4, uint64_t *accepted)
 {
-    size_t nbins = (size_t)dim->ah * dim->astride;
     float *palf = malloc(sizeof(float) * 64 * 256 * 3);
     for (int i = 0; i < 64 * 256; ++i) {
         uint32_t u[4];
@@ -860,21 +871,19 @@ double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *pa
     }
     f3_job *jobs = calloc(nthreads, sizeof(f3_job));
     pthread_t *th = calloc(nthreads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, nthreads);
     for (int t = 0; t < nthreads; ++t) {
         jobs[t] = (f3_job){dim, prog, params, palf, seeds[t % nseeds], nsamples / nthreads + (t < (int)(nsamples % nthreads)),
-                           fuse, calloc(nbins * 4, sizeof(float)), 0, t, nthreads};
+                           fuse, NULL, 0, t, nthreads, jobs, &bar, out4};
     }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, f3_worker, &jobs[t]);
     uint64_t acc = 0;
-    for (int t = 0; t < nthreads; ++t) {
-        pthread_join(th[t], NULL);
-        for (size_t i = 0; i < nbins * 4; ++i) out4[i] += jobs[t].hist[i];
-        acc += jobs[t].accepted;
-    }
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); acc += jobs[t].accepted; }
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    for (int t = 0; t < nthreads; ++t) free(jobs[t].hist);
+    pthread_barrier_destroy(&bar);
     free(jobs); free(th); free(palf);
     if (accepted) *accepted = acc;
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);

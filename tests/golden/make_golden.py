@@ -128,7 +128,12 @@ def main():
 
     # ---- 5. Profile: frame times, still quirk, wrapped scalars (profile.py:97-127)
     prof_out = {}
+    import copy
+    builtin0 = copy.deepcopy(profile.BUILTIN)
     def getp(args):
+        # the reference mutates BUILTIN[...] in place (profile.py:84-92); start each case fresh
+        profile.BUILTIN.clear()
+        profile.BUILTIN.update(copy.deepcopy(builtin0))
         return profile.get_from_args(profile.add_args().parse_args(args))
     name, prof = getp([])
     gprof = profile.wrap(prof, {'type': 'edge'})

@@ -1,0 +1,122 @@
+"""
+CPU tests (no GPU): the C-ABI library loads and exports every symbol include/flame_hip.h
+declares, host-side entry points behave, and device entry points fail loudly without a GPU.
+"""
+import ctypes as C
+import io
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+
+from common import REPO
+from cuburn_amd import _lib, render, profile, configs, output, filters, mwc
+
+
+def declared_symbols():
+    hdr = open(os.path.join(REPO, 'include', 'flame_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(fl_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(_lib.EXPORTS) == syms
+    assert lib.fl_abi_version() == 1
+
+
+def test_no_torch_or_cxx_types_in_the_abi():
+    hdr = open(os.path.join(REPO, 'include', 'flame_hip.h')).read()
+    code = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)           # declarations only, comments stripped
+    for banned in ('torch', 'at::', 'std::', 'hipStream_t', 'float4', 'template', 'class '):
+        assert banned not in code, banned
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import / link / execute anything under oracle/."""
+    for root, _, files in os.walk(os.path.join(REPO, 'cuburn_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp', 'Makefile')):
+                txt = open(os.path.join(root, f), errors='replace').read()
+                assert 'oracle' not in txt.replace('independent of oracle/', ''), os.path.join(root, f)
+                assert 'flame_ref' not in txt, os.path.join(root, f)
+
+
+def test_device_entry_points_fail_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.FlameError):
+        render.RenderManager(device=0)
+    assert b'HIP device' in _lib.load().fl_last_error() or b'gfx950' in _lib.load().fl_last_error()
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libflame_hip.so')
+    with pytest.raises(_lib.FlameError):
+        _lib.load()
+
+
+def test_renderer_host_side_objects():
+    gnm, prof = configs.cfg3()
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    assert [f.name for f in rdr.filts] == ['yuv', 'bilateral', 'logscale', 'colorclip']
+    assert len(rdr.packer) == rdr.packer.pstride
+    assert rdr.packer.packed[0] == ('camera', 'xx')
+    assert isinstance(rdr.out, output.Output)
+    assert render.Dimensions(1, 2, 3, 4, 5).astride == 5
+    # default profile filter order (specs.py:107,130)
+    gp = profile.wrap({}, gnm)
+    assert list(gp.filter_order) == ['bilateral', 'logscale', 'smearclip']
+    assert gp.width == 1280 and gp.height == 720 and gp.fps == 24
+
+
+def test_refscalar_scales_genome_spline():
+    gnm, prof = configs.cfg3()
+    gnm['camera']['spp'] = [1.0, 0, 3.0, 0]
+    gprof = profile.wrap(dict(prof, spp=100), gnm)
+    assert abs(gprof.spp(0.0) - 100) < 1e-9 and abs(gprof.spp(1.0) - 300) < 1e-9
+    assert abs(gprof.filters.logscale.scale(0.5) - gnm['camera']['scale']) < 1e-12
+
+
+def test_png_writer_roundtrip():
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (7, 5, 4)).astype(np.uint8)
+    media, logs = output.PNGOutput(alpha=True).encode(img)
+    data = media['.png'].read()
+    assert data[:8] == b'\x89PNG\r\n\x1a\n'
+    # parse IDAT back
+    pos, idat = 8, b''
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], 'big'); tag = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) & 0xffffffff == int.from_bytes(data[pos + 8 + n:pos + 12 + n], 'big')
+        if tag == b'IDAT':
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(7, 1 + 5 * 4)
+    assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(7, 5, 4), img)
+    assert output.PNGOutput().encode(None) == ({}, [])
+
+
+def test_make_seeds_shapes_and_cycling():
+    s = mwc.make_seeds(262144 + 10, host_seed=1)
+    assert s.shape == (262154, 3) and s.dtype == np.uint32
+    assert s[0, 0] == 0xFFFFFF4E and s[262144, 0] == s[0, 0]
+    assert (s[:, 1] >= 1).all() and (s[:, 2] < 0x7fffffff).all()
+
+
+def test_unknown_variation_rejected_on_host():
+    from cuburn_amd.packer import GenomePacker
+    with pytest.raises(ValueError):
+        GenomePacker({'type': 'animation', 'xforms': {'0': {'variations': {'nonesuch': {'weight': 1}}}}})
+    with pytest.raises(ValueError):
+        GenomePacker({'type': 'animation', 'xforms': {}})

@@ -1,0 +1,57 @@
+"""
+CPU test of the multi-GPU path: frame sharding + gather with world_size 2 on the gloo backend
+(the GPU run uses the same code on nccl = RCCL).
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+from common import REPO
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from cuburn_amd import distributed as D
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
+                            rank=int(os.environ['RANK']), world_size=2)
+    rank = dist.get_rank()
+    nframes = 5
+    mine = D.shard(range(nframes))
+    assert mine == list(range(nframes))[rank::2], mine
+    frames = [torch.full((4, 6, 4), 10 * i + 1, dtype=torch.uint8) for i in mine]
+    anim = D.gather_animation(frames, nframes, dst=0)
+    if rank == 0:
+        assert len(anim) == nframes
+        for i, f in enumerate(anim):
+            assert f.shape == (4, 6, 4) and int(f[0, 0, 0]) == 10 * i + 1, (i, f[0, 0, 0])
+        print('GATHER_OK')
+    else:
+        assert anim is None
+    one = D.gather_frame(torch.full((2, 2), rank, dtype=torch.int32))
+    if rank == 0:
+        assert [int(t[0, 0]) for t in one] == [0, 1]
+    dist.barrier()
+    dist.destroy_process_group()
+''') % REPO
+
+
+def test_frame_shard_and_gather_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = str(29600 + os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'GATHER_OK' in outs[0]
+
+
+def test_shard_without_process_group():
+    from cuburn_amd import distributed as D
+    assert D.shard(range(7)) == list(range(7))
+    assert D.shard(range(7), rank=1, world=3) == [1, 4]
