@@ -32,13 +32,25 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(gnm, prof, seconds):
     """flam3-style CPU chaos game (oracle/flame_ref.c ref_flam3_render) on a bounded sample."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     from common import O, prepare
     F = prepare(gnm, prof)
-    cores = os.cpu_count() or 1
-    probe = 1 << 22
+    cores = usable_cores()
+    probe = 1 << 21
     _, secs, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], probe * cores, cores)
     rate = probe * cores / max(secs, 1e-3)
     n = int(max(probe * cores, min(2 ** 31, rate * seconds)))
