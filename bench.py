@@ -67,7 +67,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (0 = skip)')
-    ap.add_argument('--accum', default=os.environ.get('FLAME_ACCUM', 'atomic'))
+    ap.add_argument('--accum', default=os.environ.get('FLAME_ACCUM', 'binned'), choices=['binned', 'atomic'])
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -86,8 +86,7 @@ def main():
     gnm, prof = configs.CONFIGS[args.config]()
     gprof = profile.wrap(prof, gnm)
     mgr = render.RenderManager(device=local, nslots=1024, host_seed=42 + rank)
-    if args.accum == 'binned':
-        mgr.accum_mode = _lib.ACCUM_BINNED
+    mgr.accum_mode = _lib.ACCUM_BINNED if args.accum == 'binned' else _lib.ACCUM_ATOMIC
     rdr = render.Renderer(gnm, gprof)
     w, h = gprof.width, gprof.height
     frame = torch.empty((h, w, 4), dtype=torch.uint8, device='cuda')

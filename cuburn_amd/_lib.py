@@ -24,7 +24,7 @@ _SIGS = {
     'fl_abi_version': (C.c_int, []),
     'fl_last_error': (C.c_char_p, []),
     'fl_calc_dim': (None, [C.c_uint32, C.c_uint32, C.POINTER(fl_dim)]),
-    'fl_ctx_create': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    'fl_ctx_create': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     'fl_ctx_destroy': (None, [C.c_void_p]),
     'fl_ctx_sync': (C.c_int, [C.c_void_p]),
     'fl_genome_create': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -45,6 +45,7 @@ _SIGS = {
                                        C.c_uint32, C.c_int]),
     'fl_debug_flush': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     'fl_debug_clear': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    'fl_debug_clear_hot': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     'fl_debug_shuffle': (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     'fl_debug_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
 }

@@ -43,6 +43,9 @@ struct fl_ctx {
     void *d_outpix = nullptr;         // w*h*8 bytes
     size_t outpix_bytes = 0;
     u64 *d_counters = nullptr;
+    uint32_t *d_log = nullptr, *d_dir = nullptr;      // binned accumulate: sample log + directory
+    size_t log_words = 0, dir_words = 0;
+    uint32_t bin_rounds = 12, bin_parts = 8;
     float *d_params = nullptr;        // [FL_NTEMPORAL * FL_MAX_PSTRIDE]
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
     uint32_t round_counter = 0;
@@ -123,7 +126,7 @@ static int ensure_fb(fl_ctx *c, const fl_dim &d)
     return FL_OK;
 }
 
-int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nslots, fl_ctx **out)
+int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out)
 {
     REQUIRE(out && seeds, "null argument");
     REQUIRE(nslots >= FL_NTEMPORAL && (nslots & (nslots - 1)) == 0, "nslots must be a power of two >= 1024");
@@ -140,16 +143,19 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nslots
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->nslots = nslots;
-    c->nwalkers = (nslots + FL_PAL_H) * 256;
     const char *env_nw = getenv("FLAME_NW");
     if (env_nw && atoi(env_nw) == 8) c->nw = 8;
+    if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_rounds = (uint32_t)v; }
+    if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
+    c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256;
+    if (nseeds != c->nwalkers) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*nw*64 + 64*256", __FILE__, __LINE__); }
     HIPCHK(hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers));
-    HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * 256));
+    HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * c->nw * 64));
     HIPCHK(hipMalloc(&c->d_counters, 8 * 4));
     HIPCHK(hipMalloc(&c->d_params, sizeof(float) * FL_NTEMPORAL * FL_MAX_PSTRIDE));
     HIPCHK(hipMalloc(&c->d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W));
     HIPCHK(hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * 256 * 4));
+    HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * c->nw * 64 * 4));
     HIPCHK(hipMemset(c->d_counters, 0, 32));
     HIPCHK(hipEventCreate(&c->ev_frame0));
     HIPCHK(hipEventCreate(&c->ev_last));
@@ -164,6 +170,7 @@ void fl_ctx_destroy(fl_ctx *c)
     hipStreamSynchronize(c->stream);
     free_fb(c);
     hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters); hipFree(c->d_params); hipFree(c->d_palette);
+    hipFree(c->d_log); hipFree(c->d_dir);
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     hipEventDestroy(c->ev_frame0); hipEventDestroy(c->ev_last);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -262,7 +269,7 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     // new frame: restart the measurement lists
     c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
     HIPCHK(hipEventRecord(c->ev_frame0, c->stream));
-    fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * 256;
+    fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * c->nw * 64;
     launch_interp_palette(c->stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, c->d_palette);
     launch_interp_params(c->stream, c->d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
                          ts, td / FL_NTEMPORAL, d);
@@ -278,25 +285,67 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
     HIPCHK(hipMemsetAsync(c->d_atom, 0, 8 * nbins, c->stream));
     HIPCHK(hipMemsetAsync(c->d_hot, 0, 4 * (nbins / 16), c->stream));
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
-    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * 256 * 4, c->stream));
+    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * c->nw * 64 * 4, c->stream));
     return FL_OK;
 }
 
-static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count)
+// Maximum write-enabled rounds of one binned launch (bounds the sample log: nslots*NT*4 B per round)
+#define FL_BIN_MAX_ROUNDS 1024u
+
+static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint32_t *tiles_x, uint32_t *nbins,
+                         uint32_t *nbatch_total)
 {
+    const uint32_t nt = (uint32_t)c->nw * 64;
+    *tiles_x = (d.astride + 127) / 128;
+    *nbins = *tiles_x * ((d.ah + 127) / 128);
+    if (*nbins > 1023) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 1023 tiles)", __FILE__, __LINE__);
+    const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
+    *nbatch_total = per_slot * c->nslots;
+    size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
+    if (lw > c->log_words) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->d_log); c->d_log = nullptr; c->log_words = 0;
+        HIPCHK(hipMalloc(&c->d_log, lw * 4));
+        c->log_words = lw;
+    }
+    if (dw > c->dir_words) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->d_dir); c->d_dir = nullptr; c->dir_words = 0;
+        HIPCHK(hipMalloc(&c->d_dir, dw * 4));
+        c->dir_words = dw;
+    }
+    return FL_OK;
+}
+
+static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count, int acc = 0)
+{
+    uint32_t tiles_x = 0, nbins = 0, nbatch_total = 0;
+    if (acc == FL_ACCUM_BINNED) {
+        if (nrounds <= fuse) return fail(FL_E_INVAL, "binned launch needs write-enabled rounds", __FILE__, __LINE__);
+        int rc = ensure_binned(c, d, nrounds - fuse, &tiles_x, &nbins, &nbatch_total);
+        if (rc) return rc;
+    }
     EvPair *e = ev_begin(c, c->iter_ev);
-    launch_iter(c->stream, c->nw, count, c->nslots, g->d_prog, c->d_params, c->d_palette, c->d_rng, c->d_points,
-                c->d_hot, c->d_atom, (float *)c->d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse);
+    launch_iter(c->stream, c->nw, count, acc, c->nslots, g->d_prog, c->d_params, c->d_palette, c->d_rng, c->d_points,
+                c->d_hot, c->d_atom, (float *)c->d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
+                tiles_x, nbins, c->bin_rounds, nbatch_total, c->d_log, c->d_dir);
     ev_end(c, e);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
+    if (acc == FL_ACCUM_BINNED) {
+        EvPair *e2 = ev_begin(c, c->flush_ev);
+        launch_accum_tiles(c->stream, c->d_log, c->d_dir, c->d_palette, c->d_atom, (float *)c->d_front, tiles_x, nbins,
+                           c->bin_parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah);
+        ev_end(c, e2);
+        HIPCHK(hipGetLastError());
+    }
     return FL_OK;
 }
 
-static int do_flush(fl_ctx *c, const fl_dim &d)
+static int do_flush(fl_ctx *c, const fl_dim &d, bool use_hot = true)
 {
     EvPair *e = ev_begin(c, c->flush_ev);
-    launch_flush(c->stream, c->d_atom, c->d_front, c->d_hot, d.ah * d.astride);
+    launch_flush(c->stream, c->d_atom, c->d_front, c->d_hot, d.ah * d.astride, use_hot);
     ev_end(c, e);
     HIPCHK(hipGetLastError());
     return FL_OK;
@@ -306,7 +355,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
                int accum_mode, uint64_t *nsamples_run)
 {
     REQUIRE(c && g, "null argument");
-    REQUIRE(accum_mode == FL_ACCUM_ATOMIC, "accumulation mode not available");
+    REQUIRE(accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED || accum_mode == 2, "bad accumulation mode");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -323,9 +372,10 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     bool first = true;
     while (rounds) {
         uint64_t n = rounds < batch * 256 ? rounds : batch * 256;
+        if (accum_mode == FL_ACCUM_BINNED && n > FL_BIN_MAX_ROUNDS) n = FL_BIN_MAX_ROUNDS;
         uint32_t f = first ? fuse : 0;
-        if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false))) return rc;
-        if ((rc = do_flush(c, d))) return rc;
+        if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false, accum_mode))) return rc;
+        if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED))) return rc;
         rounds -= n;
         batch += batch / 2;
         first = false;
@@ -416,7 +466,7 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     int rc = ensure_fb(c, d);
     if (rc) return rc;
     void *dst = dev_out ? (void *)(uintptr_t)dev_out : c->d_outpix;
-    launch_f32_to_rgba(c->stream, d, c->d_front, c->d_rng, c->nslots * 256, fmt, dst);
+    launch_f32_to_rgba(c->stream, d, c->d_front, c->d_rng, c->nslots * (uint32_t)c->nw * 64, fmt, dst);
     HIPCHK(hipGetLastError());
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_last, c->stream));
@@ -458,7 +508,7 @@ static int buf_ptr(fl_ctx *c, fl_genome *g, int which, void **p, size_t *cap)
     case FL_BUF_SIDE: *p = c->d_side; *cap = 16 * c->nbins; break;
     case FL_BUF_PARAMS: *p = c->d_params; *cap = 4 * (size_t)FL_NTEMPORAL * (g ? g->pstride : FL_MAX_PSTRIDE); break;
     case FL_BUF_PALETTE: *p = c->d_palette; *cap = 8 * FL_PAL_H * FL_PAL_W; break;
-    case FL_BUF_POINTS: *p = c->d_points; *cap = 16 * (size_t)c->nslots * 256; break;
+    case FL_BUF_POINTS: *p = c->d_points; *cap = 16 * (size_t)c->nslots * c->nw * 64; break;
     case FL_BUF_SEEDS: *p = c->d_rng; *cap = sizeof(fl_mwc) * (size_t)c->nwalkers; break;
     case FL_BUF_ATOM: *p = c->d_atom; *cap = 8 * c->nbins; break;
     case FL_BUF_HOT: *p = c->d_hot; *cap = 4 * (c->nbins / 16); break;
@@ -505,14 +555,14 @@ int fl_debug_clear(fl_ctx *c, uint32_t w, uint32_t h, int reset_points)
 int fl_debug_iter_launch(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, uint32_t round0,
                          uint32_t nrounds, uint32_t fuse, int accum_mode)
 {
-    REQUIRE(c && g && accum_mode == FL_ACCUM_ATOMIC, "bad argument");
+    REQUIRE(c && g && (accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED), "bad argument");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
     c->round_counter = round0;
     HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
-    return do_iter_launch(c, g, d, nrounds, fuse, true);
+    return do_iter_launch(c, g, d, nrounds, fuse, true, accum_mode);
 }
 
 int fl_debug_flush(fl_ctx *c, uint32_t w, uint32_t h)
@@ -522,6 +572,14 @@ int fl_debug_flush(fl_ctx *c, uint32_t w, uint32_t h)
     int rc = ensure_fb(c, d);
     if (rc) return rc;
     return do_flush(c, d);
+}
+
+int fl_debug_clear_hot(fl_ctx *c, uint32_t w, uint32_t h)
+{
+    REQUIRE(c && c->d_hot, "null ctx");
+    fl_dim d; fl_calc_dim(w, h, &d);
+    HIPCHK(hipMemsetAsync(c->d_hot, 0, 4 * ((size_t)d.ah * d.astride / 16), c->stream));
+    return FL_OK;
 }
 
 int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)

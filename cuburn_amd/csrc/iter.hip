@@ -70,25 +70,56 @@ __device__ __forceinline__ void reseed(float &x, float &y, float &c, mwc_t &r) {
     x = mwc_next_11(r); y = mwc_next_11(r); c = mwc_next_01(r);
 }
 
+// Geometry of the binned accumulate (FL_ACCUM_BINNED): the image is cut into 128x128-pixel tiles
+// ("bins"); a sample record is 22 bits {offset in tile 14, palette column 8}; a staged record
+// carries its bin number above that.
+struct BinGeom {
+    uint32_t tiles_x;        // tiles per row
+    uint32_t nbins;          // number of tiles B (<= 1023)
+    uint32_t rounds;         // R: write-enabled rounds per batch
+    uint32_t nbatch_total;   // batches of this launch = nslots * batches per slot
+    uint32_t *log;           // [nbatch_total * R * NT] sorted records
+    uint32_t *dir;           // [B][nbatch_total] (first record << 16) | count
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
 // counters: [0] accepted, [1] out of frame, [2] dropped by hot-pixel roulette, [3] spills
-template <int NW, bool COUNT>
+// ACC: 0 = packed global atomics, 1 = binned (sample log), 2 = none (measurement of the walk)
+template <int NW, bool COUNT, int ACC>
 __global__ void __launch_bounds__(NW * 64)
 k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
        const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points,
        const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4,
        u64 *__restrict__ counters, uint32_t astride, uint32_t aheight,
-       uint32_t round0, uint32_t nrounds, uint32_t fuse)
+       uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg)
 {
     constexpr int NT = NW * 64;
-    __shared__ float swp[2][3][NT];
-    __shared__ u64 palrow[FL_PAL_W];
+    // all LDS is carved from the dynamic region (16-byte aligned pieces)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float (*swp)[3][NT] = reinterpret_cast<float (*)[3][NT]>(smem);                    // [2][3][NT]
+    u64 *palrow = reinterpret_cast<u64 *>(smem + 2 * 3 * NT * 4);                      // [256]   (ACC != 1)
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (ACC == 1)
+    uint32_t *sorted = stage + bg.rounds * NT;                                         // [R*NT]
+    uint32_t *cnt = sorted + bg.rounds * NT;                                           // [B+1]
+    uint32_t *cur = cnt + ((bg.nbins + 1 + 3) & ~3u);                                  // [B+1]
+    uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const uint32_t slot = blockIdx.x, ts = slot & (FL_NTEMPORAL - 1);
     const int nxf = prog[1], has_final = prog[2], pstride = prog[3], cdf_off = prog[4];
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
-    for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
+    if (ACC != 1) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
+    if (ACC == 1) for (uint32_t i = tid; i <= bg.nbins; i += NT) cnt[i] = 0;
+    uint32_t staged = 0, batch_in_slot = 0;
 
     const size_t wi = (size_t)slot * NT + tid;
     mwc_t rctx = {rng[wi].mul, rng[wi].state, rng[wi].carry};
@@ -133,7 +164,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         const uint32_t gi = ok ? iy * astride + ix : 0u;
 
         float mult = 1.0f;
-        if (ok) {                                                           // iter.py:319-329
+        if (ok && ACC != 1) {                                               // iter.py:319-329
             const uint32_t flag = (hot[gi >> 4] >> ((gi & 15u) << 1)) & 3u;
             if (flag) {
                 mult = hot_mult(flag);
@@ -142,20 +173,64 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         }
         const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
         const int ci = (int)__builtin_rintf(fminf(fmaxf(cf, 0.0f), 255.0f));
-        const u64 val = palrow[ci];                                         // iter.py:351
+        const u64 val = ACC == 1 ? 0ull : palrow[ci];                       // iter.py:351
 
         // Every add returns the previous cell value, but the value is only looked at one
         // round later (pend_*), so its latency hides under the next round's work.  A cell seen
         // at >= 512 hits is drained into the float accumulator before its 10-bit count can
         // wrap.  (The reference checks 3 % of warp-rounds synchronously, iter.py:361-406; with
         // wave-coherent hits that leaves a real chance of wrapping on concentrated flames.)
-        drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
-        pend_ok = ok; pend_gi = gi; pend_mult = mult;
-        if (ok) pend_old = __hip_atomic_fetch_add(atom + gi, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ACC == 0) {
+            drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
+            pend_ok = ok; pend_gi = gi; pend_mult = mult;
+            if (ok) pend_old = __hip_atomic_fetch_add(atom + gi, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (ACC == 1) {
+            // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
+            // and written to this slot's private region of the sample log (no global atomics)
+            const uint32_t bin = ok ? (iy >> 7) * bg.tiles_x + (ix >> 7) : bg.nbins;
+            const uint32_t rec = (bin << 22) | ((iy & 127u) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
+            stage[staged * NT + tid] = rec;
+            __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (++staged == bg.rounds || rd + 1 == nrounds) {
+                const uint32_t n = staged * NT;
+                const uint32_t batch_id = batch_in_slot * gridDim.x + slot;
+                __syncthreads();
+                if (w == 0) {                       // exclusive scan of the bin counts, directory entries
+                    uint32_t running = 0;
+                    for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
+                        const uint32_t b = c0 + l;
+                        const uint32_t v = b <= bg.nbins ? cnt[b] : 0u;
+                        const uint32_t incl = wave_incl_scan(v, l);
+                        const uint32_t excl = incl - v + running;
+                        if (b <= bg.nbins) { cur[b] = excl; cnt[b] = 0; }
+                        if (b < bg.nbins) bg.dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+                        if (b == bg.nbins) *s_nvalid = excl;
+                        running += __shfl(incl, 63);
+                    }
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += NT) {
+                    const uint32_t r2 = stage[i];
+                    const uint32_t pos = __hip_atomic_fetch_add(cur + (r2 >> 22), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    sorted[pos] = r2 & 0x3fffffu;
+                }
+                __syncthreads();
+                const uint32_t nvalid = *s_nvalid;
+                uint4 *dst = reinterpret_cast<uint4 *>(bg.log + (size_t)batch_id * bg.rounds * NT);
+                const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
+                for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
+                staged = 0; ++batch_in_slot;
+                __syncthreads();
+            }
+        } else {
+            // measurement mode: everything but the accumulate (ceiling of the walk itself)
+            pend_old += ok ? val + gi : 0ull;
+        }
         if (COUNT) n_acc += ok;
     }
 
-    drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
+    if (ACC == 0) drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
+    else if (pend_old == 0x123456789abcdefull) atom[0] = pend_old;
     points[wi] = make_float4(x, y, color, 0.0f);                            // iter.py:414-416
     rng[wi].mul = rctx.mul; rng[wi].state = rctx.state; rng[wi].carry = rctx.carry;
 
@@ -182,12 +257,12 @@ __global__ void __launch_bounds__(NW * 64) k_shuffle_tap(uint32_t *out, uint32_t
 // the hot-flag weight that was in force while they filled, zero them, and recompute the 2-bit
 // flags (16 pixels per u32 word at gi >> 4) from the accumulated density.
 __global__ void __launch_bounds__(256)
-k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__ hot, uint32_t nbins)
+k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__ hot, uint32_t nbins, int use_hot)
 {
     const uint32_t gi = blockIdx.x * 256u + threadIdx.x;      // nbins is a multiple of 512
     if (gi >= nbins) return;
     const uint32_t sh = (gi & 15u) << 1;
-    const uint32_t flag = (hot[gi >> 4] >> sh) & 3u;
+    const uint32_t flag = use_hot ? (hot[gi >> 4] >> sh) & 3u : 0u;     // binned mode never thins samples
     const float mult = hot_mult(flag);
     const u64 cell = __builtin_nontemporal_load(atom + gi);
     __builtin_nontemporal_store(0ull, atom + gi);
@@ -210,21 +285,41 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 }
 
 // ---- host-side launchers --------------------------------------------------------------------
-void launch_iter(hipStream_t st, int nw, bool count, uint32_t nslots,
+static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
+{
+    size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
+    if (acc == 1) b += 2 * (size_t)rounds * nt * 4 + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
+    else b += FL_PAL_W * 8;
+    return b;
+}
+
+void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
                  float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
-                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse)
+                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
+                 uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
+                 uint32_t *log, uint32_t *dir)
 {
-#define LAUNCH(NW, C) hipLaunchKernelGGL((k_iter<NW, C>), dim3(nslots), dim3(NW * 64), 0, st, prog, params, palette, \
-        rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse)
-    if (nw == 4) { if (count) LAUNCH(4, true); else LAUNCH(4, false); }
-    else if (nw == 8) { if (count) LAUNCH(8, true); else LAUNCH(8, false); }
+    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, log, dir};
+    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins);
+#define LAUNCH(NW, C, A) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { hipFuncSetAttribute((const void *)k_iter<NW, C, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        hipLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, prog, params, palette, \
+        rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg); } while (0)
+    if (acc == 2) { if (nw == 4) LAUNCH(4, false, 2); else LAUNCH(8, false, 2); }
+    else if (acc == 1) {
+        if (nw == 4) { if (count) LAUNCH(4, true, 1); else LAUNCH(4, false, 1); }
+        else { if (count) LAUNCH(8, true, 1); else LAUNCH(8, false, 1); }
+    }
+    else if (nw == 4) { if (count) LAUNCH(4, true, 0); else LAUNCH(4, false, 0); }
+    else if (nw == 8) { if (count) LAUNCH(8, true, 0); else LAUNCH(8, false, 0); }
 #undef LAUNCH
 }
 
-void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins)
+void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot)
 {
-    hipLaunchKernelGGL(k_flush, dim3((nbins + 255) / 256), dim3(256), 0, st, atom, out, hot, nbins);
+    hipLaunchKernelGGL(k_flush, dim3((nbins + 255) / 256), dim3(256), 0, st, atom, out, hot, nbins, use_hot ? 1 : 0);
 }
 
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round)

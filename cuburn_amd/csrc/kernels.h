@@ -7,12 +7,20 @@
 typedef unsigned long long u64;
 
 // iter.hip
-void launch_iter(hipStream_t st, int nw, bool count, uint32_t nslots,
+void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
                  float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
-                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse);
-void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins);
+                 uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
+                 uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
+                 uint32_t *log, uint32_t *dir);
+void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot);
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
+
+// binned.hip
+void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
+                        u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,
+                        uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
+                        uint32_t astride, uint32_t aheight);
 
 // interp.hip
 void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes, const float4 *pals,

@@ -61,10 +61,12 @@ class Framebuffers(object):
     def __init__(self, device=0, nslots=1024, host_seed=None, stream=None):
         lib = _lib.load()
         self.nslots = nslots
-        self.nwalkers = (nslots + 64) * 256
+        self.nw = 8 if os.environ.get('FLAME_NW') == '8' else 4       # waves per iterate workgroup
+        self.nthreads = self.nw * 64
+        self.nwalkers = nslots * self.nthreads + 64 * 256
         seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, host_seed))
         ctx = C.c_void_p()
-        _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, nslots, C.byref(ctx)))
+        _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, self.nwalkers, nslots, C.byref(ctx)))
         self.ctx = ctx
         self._host = {}
 
@@ -139,7 +141,9 @@ class Renderer(object):
 class RenderManager(object):
     """Frame queue (cuburn/render.py:253-434)."""
 
-    accum_mode = _lib.ACCUM_ATOMIC
+    # 'auto': binned accumulate (sample log + LDS tiles) whenever the image has <= 1023 tiles of
+    # 128x128 pixels (up to 4K), else direct packed global atomics.  Both give the same histogram.
+    accum_mode = 'auto'
     fuse = 256                      # write-disabled iterations per walker per frame (render.py:215)
 
     def __init__(self, device=None, nslots=1024, host_seed=None, stream=None):
@@ -174,8 +178,11 @@ class RenderManager(object):
         _lib.check(lib.fl_interp(self.fb.ctx, g, dim.w, dim.h, ts, td))
         nsamps = gprof.spp(tc) * dim.w * dim.h
         run = C.c_uint64()
-        _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse, self.accum_mode,
-                                  C.byref(run)))
+        mode = self.accum_mode
+        if mode == 'auto':
+            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 127) // 128)
+            mode = _lib.ACCUM_BINNED if ntiles <= 1023 else _lib.ACCUM_ATOMIC
+        _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse, mode, C.byref(run)))
         self.last_nsamples = run.value
         for filt in rdr.filts:
             params = getattr(gprof.filters, filt.name)

@@ -132,9 +132,10 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
 
 /* cuburn/render.py:253-262 RenderManager.__init__ + :91-104 Framebuffers.__init__:
  * device, streams, walker/RNG state (persistent across frames, render.py:95-104).
- * `seeds` = nwalkers x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
- * nwalkers must be (nslots + FL_PAL_H) * 256.  stream = hipStream_t or NULL. */
-int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nslots, fl_ctx **out);
+ * `seeds` = nseeds x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
+ * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 with NW = waves per iterate workgroup
+ * (4; 8 when the environment says FLAME_NW=8).  stream = hipStream_t or NULL. */
+int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out);
 void fl_ctx_destroy(fl_ctx *ctx);
 int fl_ctx_sync(fl_ctx *ctx);
 
@@ -215,6 +216,7 @@ int fl_debug_iter_launch(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, uint
                          uint32_t nrounds, uint32_t fuse, int accum_mode);
 int fl_debug_flush(fl_ctx *ctx, uint32_t w, uint32_t h);
 int fl_debug_clear(fl_ctx *ctx, uint32_t w, uint32_t h, int reset_points);
+int fl_debug_clear_hot(fl_ctx *ctx, uint32_t w, uint32_t h);
 /* Point-shuffle tap: out[dst_thread] = src_thread after one swap with round counter `round`. */
 int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */

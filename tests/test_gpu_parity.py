@@ -83,9 +83,13 @@ def test_palette_bit_exact(mgr):
     assert np.array_equal(seeds2[NSLOTS * 256:], rng_after)
 
 
-def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1):
-    """GPU and oracle from the same device params / palette / seeds / points; returns both states."""
+def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1, mode=0, seeds_in=None):
+    """GPU and oracle from the same device params / palette / seeds / points; returns both states.
+    mode 0 = packed global atomics (hot flags + roulette live), 1 = binned (no sample thinning)."""
     lib = _lib.load()
+    if seeds_in is not None:                # before interp: the palette kernel draws from these too
+        mgr.fb.write('seeds', seeds_in)
+    seeds0 = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
     rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof)
     d = O.calc_dim(dim.w, dim.h)
     nbins = dim.ah * dim.astride
@@ -102,21 +106,27 @@ def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1):
     r0 = 0
     for k in range(launches):
         f = fuse if k == 0 else 0
-        _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, r0, nrounds + f, f, 0))
+        _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, r0, nrounds + f, f, mode))
         ctr_ref = O.iter_launch(O.GEOM_4x64, d, rdr.packer.prog, params, palette, rng, points, NSLOTS,
                                 hot, atom, out4, r0, nrounds + f, f)
         ctr_dev = np.zeros(4, np.uint64)
         _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr_dev.ctypes.data))
         dev_atom = mgr.fb.read('atom', (nbins,), np.uint64)
         res.append(dict(ctr_ref=ctr_ref.copy(), ctr_dev=ctr_dev, atom_ref=atom.copy(), atom_dev=dev_atom))
+        if mode == 1:                       # binned mode never thins: flags are neither read nor kept
+            _lib.check(lib.fl_debug_clear_hot(mgr.fb.ctx, dim.w, dim.h))
+            hot[:] = 0
         _lib.check(lib.fl_debug_flush(mgr.fb.ctx, dim.w, dim.h))
         O.flush(d, atom, out4, hot)
+        if mode == 1:
+            _lib.check(lib.fl_debug_clear_hot(mgr.fb.ctx, dim.w, dim.h))
+            hot[:] = 0
         res[-1].update(front_dev=mgr.fb.read('front', (nbins, 4), np.float32), front_ref=out4.copy(),
                        hot_dev=mgr.fb.read('hot', (nbins // 16,), np.uint32), hot_ref=hot.copy())
         r0 += nrounds + f
     dev_rng = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)[:NSLOTS * 256]
     dev_pts = mgr.fb.read('points', (NSLOTS * 256, 4), np.float32)
-    return res, (rng, points), (dev_rng, dev_pts), dim
+    return res, (rng, points), (dev_rng, dev_pts), dim, seeds0
 
 
 def linear_flame():
@@ -132,7 +142,7 @@ def linear_flame():
 
 def test_iter_bit_exact_linear(mgr):
     gnm, prof = linear_flame()
-    res, ref_state, dev_state, dim = run_device_model(mgr, gnm, prof, nrounds=8, fuse=5, launches=2)
+    res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=8, fuse=5, launches=2)
     for k, r in enumerate(res):
         assert int(r['ctr_dev'][3]) == 0 and int(r['ctr_ref'][3]) == 0, 'spill path taken; shrink the test'
         assert np.array_equal(r['ctr_dev'][:3], r['ctr_ref'][:3]), (k, r['ctr_dev'], r['ctr_ref'])
@@ -165,7 +175,7 @@ def test_iter_hot_pixels_and_spill(mgr):
     implementation of this cell format, the reference included; see DESIGN.md.)
     """
     gnm, prof = hot_flame()
-    res, ref_state, dev_state, dim = run_device_model(mgr, gnm, prof, nrounds=16, fuse=16, launches=4)
+    res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=16, fuse=16, launches=4)
     last = res[-1]
     assert (last['hot_dev'] != 0).any(), 'expected hot pixels'
     assert int(last['ctr_dev'][2]) > 0, 'expected roulette drops'
@@ -179,11 +189,44 @@ def test_iter_hot_pixels_and_spill(mgr):
     assert np.array_equal(dev_state[0], ref_state[0])
 
 
+def test_binned_equals_atomic_equals_oracle(mgr):
+    """The binned accumulate (LDS tile sort -> sample log -> LDS tile atomics -> coalesced packed
+    adds) produces the same packed histogram, bit for bit, as direct global atomics and as the
+    oracle: integer adds commute.  Odd round counts exercise a partial last batch."""
+    gnm, prof = linear_flame()
+    prof = dict(prof, width=1920, height=1080)
+    gnm['camera']['scale'] = 1.0          # zoomed in: every cell stays below the 128-hit packed-add limit
+    res_a, ref_a, dev_a, dim, seeds = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=0)
+    res_b, ref_b, dev_b, dim, _ = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=1, seeds_in=seeds)
+    a, b = res_a[0], res_b[0]
+    assert int(a['ctr_dev'][3]) == 0
+    assert np.array_equal(a['ctr_dev'][:2], b['ctr_dev'][:2])
+    assert np.array_equal(a['atom_dev'], a['atom_ref'])
+    assert np.array_equal(b['atom_dev'], a['atom_dev'])
+    assert np.array_equal(b['front_dev'], a['front_dev'])
+    assert np.array_equal(dev_a[0], dev_b[0]) and np.array_equal(dev_a[1][:, :3], dev_b[1][:, :3])
+
+
+def test_binned_hot_region_exact_density(mgr):
+    """Binned mode on the hot-region flame, 3 launches: drains happen in LDS and at the tile add;
+    density must still be exact against the oracle run without hot-pixel thinning."""
+    gnm, prof = hot_flame()
+    res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=40, fuse=16, launches=3, mode=1)
+    for k, r in enumerate(res):
+        assert np.array_equal(r['ctr_dev'][:2], r['ctr_ref'][:2]), (k, r['ctr_dev'], r['ctr_ref'])
+        assert int(r['ctr_dev'][2]) == 0
+        nd = int((r['front_dev'][:, 3] != r['front_ref'][:, 3]).sum())
+        assert nd == 0, (k, nd)
+        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=2e-6, atol=1e-4)
+    assert np.array_equal(dev_state[0], ref_state[0])
+
+
 def density(front, dim):
     return front[:, 3].reshape(dim.ah, dim.astride).astype(np.float64)
 
 
-def test_iter_distribution_cfg2(mgr):
+@pytest.mark.parametrize('mode', [0, 1])
+def test_iter_distribution_cfg2(mgr, mode):
     """
     Flame with hardware transcendentals (spherical, swirl): GPU histogram vs the flam3-style CPU
     chaos game (independent per-sample xform choice).  Criteria: relative L1 of
@@ -199,7 +242,7 @@ def test_iter_distribution_cfg2(mgr):
     lib = _lib.load()
     _lib.check(lib.fl_interp(mgr.fb.ctx, g, dim.w, dim.h, 0.5, 0.0))
     run = C.c_uint64()
-    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 26), 256, 0, C.byref(run)))
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 26), 256, mode, C.byref(run)))
     nbins = dim.ah * dim.astride
     front = mgr.fb.read('front', (nbins, 4), np.float32)
     n_gpu = run.value

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t mwc(uint32_t &s, uint32_t &c, uint32_t a) {
 }
 
 enum { M_AGENT = 0, M_WG_XCD = 1, M_AGENT_RTN = 2, M_STORE = 3, M_AGENT_U32 = 4, M_AGENT_F32 = 5, M_SYSTEM = 6 };
-enum { D_UNIFORM = 0, D_IFS = 1, D_HOT = 2 };
+enum { D_UNIFORM = 0, D_IFS = 1, D_HOT = 2, D_COAL = 3, D_WINDOW = 4, D_PAIRS = 5 };
 
 // width/height in cells; layout 0 = row-major, 1 = 4x4 tiles (one 128-B line per tile)
 template <int MODE, int DIST, int LAYOUT>
@@ -42,6 +42,18 @@ __global__ void __launch_bounds__(256) k_scatter(u64 *hist, size_t copy_stride, 
         if (DIST == D_UNIFORM) {
             ix = (uint32_t)(((u64)r * (uint32_t)width) >> 32);
             iy = (uint32_t)(((u64)mwc(s, c, a) * (uint32_t)height) >> 32);
+        } else if (DIST == D_COAL || DIST == D_WINDOW || DIST == D_PAIRS) {
+            // wave-level patterns: a random base per wave (lane 0's draw), then
+            //   COAL:   lane l -> base + l            (64 consecutive cells = 4 lines)
+            //   WINDOW: lane l -> base + random(512)  (same 4 KB window)
+            //   PAIRS:  lane l -> base + (l/2)*977    (two lanes per cell, cells scattered)
+            uint32_t ru = __builtin_amdgcn_readfirstlane(r);
+            uint32_t cells = (uint32_t)width * (uint32_t)height;
+            uint32_t base_i = (uint32_t)(((u64)ru * (cells - 65536u)) >> 32);
+            uint32_t lane = threadIdx.x & 63;
+            uint32_t off = DIST == D_COAL ? lane : (DIST == D_WINDOW ? (mwc(s, c, a) & 511u) : (lane >> 1) * 977u);
+            uint32_t lin = base_i + off;
+            ix = lin % (uint32_t)width; iy = lin / (uint32_t)width;
         } else {
             // wave-uniform map choice like the flame kernel: use lane-0's r
             uint32_t ru = __builtin_amdgcn_readfirstlane(r);
@@ -154,6 +166,12 @@ int main() {
         run<M_AGENT_U32, D_UNIFORM, 0>("agent u32    uniform rowmajor", hist, cs, 1, w, h, sink, hbuf);
         run<M_AGENT_F32, D_UNIFORM, 0>("agent f32    uniform rowmajor", hist, cs, 1, w, h, sink, hbuf);
         run<M_SYSTEM,    D_UNIFORM, 0>("system nortn uniform rowmajor", hist, cs, 1, w, h, sink, hbuf);
+        run<M_AGENT,     D_COAL, 0>("agent  nortn wave-coalesced 64 cells", hist, cs, 1, w, h, sink, hbuf);
+        run<M_AGENT,     D_WINDOW, 0>("agent  nortn wave in 4KB window", hist, cs, 1, w, h, sink, hbuf);
+        run<M_AGENT,     D_PAIRS, 0>("agent  nortn lane pairs same cell", hist, cs, 1, w, h, sink, hbuf);
+        run<M_AGENT_U32, D_COAL, 0>("agent u32 wave-coalesced", hist, cs, 1, w, h, sink, hbuf);
+        run<M_AGENT_F32, D_COAL, 0>("agent f32 wave-coalesced", hist, cs, 1, w, h, sink, hbuf);
+        run<M_STORE,     D_COAL, 0>("plain store wave-coalesced", hist, cs, 1, w, h, sink, hbuf);
         run<M_AGENT,     D_IFS, 0>("agent  nortn ifs     rowmajor", hist, cs, 1, w, h, sink, hbuf);
         run<M_AGENT,     D_IFS, 1>("agent  nortn ifs     tiled4x4", hist, cs, 1, w, h, sink, hbuf);
         run<M_WG_XCD,    D_IFS, 0>("wg/xcd nortn ifs     rowmajor", hist, cs, 8, w, h, sink, hbuf);
