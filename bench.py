@@ -93,34 +93,38 @@ def main():
     gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
     tc = 0.5
 
-    def step():
-        evt, h_out = mgr.queue_frame(rdr, gnm, gprof, tc)
+    def finish(evt, h_out):
+        """Wait for a queued frame; multi-GPU: hand it to the RCCL gather (frames are the only exchange)."""
+        evt.synchronize()
         if world > 1:
-            # finished frame -> device tensor -> RCCL gather to rank 0 (frames are the only exchange)
-            evt.synchronize()
             frame.copy_(torch.from_numpy(h_out), non_blocking=False)
             dist.gather(frame, gathered, dst=0)
-        return evt
+
+    def run(nframes):
+        """The double-buffered frame loop of the reference (main.py:64-76): queue frame k+1, then wait for frame k."""
+        pending = None
+        for _ in range(nframes):
+            nxt = mgr.queue_frame(rdr, gnm, gprof, tc)
+            if pending is not None:
+                finish(*pending)
+            pending = nxt
+        if pending is not None:
+            finish(*pending)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step().synchronize()
+    run(args.warmup)
     fence()
-    acc = dict(iter_ms=0.0, flush_ms=0.0, filter_ms=0.0, launches=0, samples=0)
+    mgr.timings_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        evt = step()
-        evt.synchronize()
-        t = mgr.timings()
-        for k in ('iter_ms', 'flush_ms', 'filter_ms', 'launches'):
-            acc[k] += t[k]
-        acc['samples'] += mgr.last_nsamples
+    run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    acc = mgr.timings()
+    acc['samples'] = mgr.last_nsamples * args.steps
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

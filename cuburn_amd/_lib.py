@@ -36,7 +36,12 @@ _SIGS = {
                              C.POINTER(C.c_uint64)]),
     'fl_filter': (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
     'fl_output': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64]),
-    'fl_frame_ms': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'fl_frame_begin': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    'fl_frame_ms': (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
+    'fl_frame_query': (C.c_int, [C.c_void_p, C.c_uint32]),
+    'fl_host_alloc': (C.c_void_p, [C.c_size_t]),
+    'fl_host_free': (None, [C.c_void_p]),
+    'fl_timings_reset': (C.c_int, [C.c_void_p]),
     'fl_timings': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.POINTER(C.c_uint32)]),
     'fl_read_buffer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),

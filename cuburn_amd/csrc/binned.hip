@@ -1,18 +1,19 @@
 // binned.hip — second half of the binned accumulate (FL_ACCUM_BINNED).
 //
 // k_iter (ACC == 1) leaves, per launch, a sample log: for every (slot, batch) a block of
-// 22-bit records sorted by image tile, plus a directory dir[tile][batch] = (first << 16) | count.
-// k_accum_tiles gives each 128x128-pixel tile to P workgroups (contiguous ranges of batches);
+// 21-bit records sorted by image tile, plus a directory dir[tile][batch] = (first << 16) | count.
+// k_accum_tiles gives each 128x64-pixel tile to P workgroups (contiguous ranges of batches);
 // a workgroup accumulates its share into an LDS tile of packed 64-bit cells with LDS atomics,
 // then adds the tile to the global packed accumulator with COALESCED 64-bit atomics (64
 // consecutive cells per wave instruction: 7x the throughput of scattered atomics on MI355X,
 // profiles/r01_atomic_microbench*.txt).  Cells that fill up (>= 512 hits) are drained into the
 // float accumulator exactly as in the direct path (cuburn/code/iter.py:366-406).
+//
+// The kernel is latency bound (directory -> record -> palette -> LDS atomic is a dependent
+// chain), so: 64 KB tiles (two 1024-thread workgroups = 32 waves per CU) and four independent
+// records per lane in flight.
 #include "flame_device.h"
 #include "kernels.h"
-
-#define TILE_W 128
-#define TILE_CELLS (128 * 128)
 
 __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restrict__ out4)
 {
@@ -34,6 +35,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_b(uint32_t v, uint32_t lane) 
     return v;
 }
 
+#define ACC_ILP 4
+
 __global__ void __launch_bounds__(1024)
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
@@ -41,12 +44,12 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
               uint32_t nslots, uint32_t astride, uint32_t aheight)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *tile = reinterpret_cast<u64 *>(smem);                     // [TILE_CELLS]
+    u64 *tile = reinterpret_cast<u64 *>(smem);                     // [FL_TILE_CELLS]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
 
-    for (uint32_t i = tid; i < TILE_CELLS; i += blockDim.x) tile[i] = 0ull;
+    for (uint32_t i = tid; i < FL_TILE_CELLS; i += blockDim.x) tile[i] = 0ull;
     __syncthreads();
 
     // this workgroup's contiguous range of batches
@@ -55,36 +58,45 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const uint32_t *drow = dir + (size_t)bin * nbatch_total;
 
     for (uint32_t g0 = b_lo + wv * 64; g0 < b_hi; g0 += nwaves * 64) {
-        // 64 directory entries per wave; pack their runs into one virtual array
+        // 64 directory entries per wave; their runs form one virtual array of `total` records
         const uint32_t batch = g0 + lane;
         const uint32_t e = batch < b_hi ? drow[batch] : 0u;
         const uint32_t c = e & 0xffffu, first = e >> 16;
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
         const uint32_t total = __shfl(incl, 63);
-        for (uint32_t v0 = 0; v0 < total; v0 += 64) {
-            const uint32_t v = v0 + lane;
-            // rightmost run r with excl[r] <= v  (binary search over the 64 lanes' values)
-            uint32_t r = 0;
+        for (uint32_t v0 = 0; v0 < total; v0 += 64 * ACC_ILP) {
+            uint32_t rec[ACC_ILP], row[ACC_ILP];
+            bool live[ACC_ILP];
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const uint32_t probe = r + step;
-                const uint32_t pe = __shfl(excl, probe & 63);
-                if (probe < 64 && pe <= v) r = probe;
-            }
-            const uint32_t r_excl = __shfl(excl, r), r_first = __shfl(first, r);
-            if (v < total) {
+            for (int k = 0; k < ACC_ILP; ++k) {
+                const uint32_t v = v0 + k * 64 + lane;
+                // rightmost run r with excl[r] <= v (binary search over the 64 lanes' values)
+                uint32_t r = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const uint32_t probe = r + step;
+                    const uint32_t pe = __shfl(excl, probe & 63);
+                    if (probe < 64 && pe <= v) r = probe;
+                }
+                const uint32_t r_excl = __shfl(excl, r), r_first = __shfl(first, r);
+                live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
-                const uint32_t rec = log[(size_t)rbatch * batch_records + r_first + (v - r_excl)];
-                const uint32_t slot = rbatch % nslots;
-                const uint32_t row = (slot & (FL_NTEMPORAL - 1)) >> 4;
-                const u64 val = palette[row * FL_PAL_W + (rec & 0xffu)];
-                const uint32_t off = rec >> 8;                                   // (ly << 7) | lx
-                const u64 old = __hip_atomic_fetch_add(tile + off, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rec[k] = live[k] ? log[(size_t)rbatch * batch_records + r_first + (v - r_excl)] : 0u;
+                row[k] = ((rbatch % nslots) & (FL_NTEMPORAL - 1)) >> 4;
+            }
+            u64 val[ACC_ILP];
+#pragma unroll
+            for (int k = 0; k < ACC_ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+#pragma unroll
+            for (int k = 0; k < ACC_ILP; ++k) {
+                if (!live[k]) continue;
+                const uint32_t off = rec[k] >> 8;                                // (ly << 7) | lx
+                const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if ((uint32_t)(old >> 32) >= (256u << 23)) {
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
-                        const uint32_t px = tx * TILE_W + (off & 127u), py = ty * TILE_W + (off >> 7);
+                        const uint32_t px = tx * FL_TILE_W + (off & 127u), py = ty * FL_TILE_H + (off >> 7);
                         spill_cell(cur, py * astride + px, out4);
                     }
                 }
@@ -95,9 +107,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 
     // add the tile to the global packed accumulator: one row segment of 64 cells per wave
     // instruction (coalesced atomics), draining cells that reach 512 hits
-    for (uint32_t i = tid; i < TILE_CELLS; i += blockDim.x) {
+    for (uint32_t i = tid; i < FL_TILE_CELLS; i += blockDim.x) {
         const u64 v = tile[i];
-        const uint32_t px = tx * TILE_W + (i & 127u), py = ty * TILE_W + (i >> 7);
+        const uint32_t px = tx * FL_TILE_W + (i & 127u), py = ty * FL_TILE_H + (i >> 7);
         if (v != 0ull && px < astride && py < aheight) {
             const uint32_t gi = py * astride + px;
             // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
@@ -118,11 +130,6 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
                         uint32_t astride, uint32_t aheight)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)k_accum_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k_accum_tiles, dim3(nbins * nparts), dim3(1024), TILE_CELLS * 8, st, log, dir, palette, atom, out4,
+    hipLaunchKernelGGL(k_accum_tiles, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8, st, log, dir, palette, atom, out4,
                        tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
 }

@@ -45,11 +45,13 @@ struct fl_ctx {
     u64 *d_counters = nullptr;
     uint32_t *d_log = nullptr, *d_dir = nullptr;      // binned accumulate: sample log + directory
     size_t log_words = 0, dir_words = 0;
-    uint32_t bin_rounds = 12, bin_parts = 8;
+    uint32_t bin_rounds = 12, bin_parts = 16;
     float *d_params = nullptr;        // [FL_NTEMPORAL * FL_MAX_PSTRIDE]
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
     uint32_t round_counter = 0;
-    hipEvent_t ev_frame0 = nullptr, ev_last = nullptr;
+    static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
+    hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
+    uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
     std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev;
     size_t pool_used = 0;
     bool timing = true;
@@ -62,6 +64,13 @@ struct fl_genome {
     float *d_times = nullptr, *d_knots = nullptr, *d_ptimes = nullptr;
     float4 *d_pals = nullptr;
     uint32_t npal = 0;
+    // pinned staging for asynchronous uploads: a small ring so that packing frame k+1 on the
+    // host never overwrites bytes a queued copy of frame k still has to read
+    static const int kStage = 4;
+    unsigned char *h_stage[kStage] = {};
+    hipEvent_t ev_stage[kStage] = {};
+    size_t stage_bytes = 0;
+    int stage_next = 0;
 };
 
 static const int kKnownVars[] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,
@@ -79,7 +88,7 @@ static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
     EvPair p = c->pool[c->pool_used++];
     list.push_back(p);
     hipEventRecord(p.a, c->stream);
-    return &list.back();
+    return &c->pool[c->pool_used - 1];
 }
 static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, c->stream); }
 
@@ -157,8 +166,10 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     HIPCHK(hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * c->nw * 64 * 4));
     HIPCHK(hipMemset(c->d_counters, 0, 32));
-    HIPCHK(hipEventCreate(&c->ev_frame0));
-    HIPCHK(hipEventCreate(&c->ev_last));
+    for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) {
+        HIPCHK(hipEventCreate(&c->ev_begin_[i]));
+        HIPCHK(hipEventCreate(&c->ev_end_[i]));
+    }
     *out = c;
     return FL_OK;
 }
@@ -172,7 +183,7 @@ void fl_ctx_destroy(fl_ctx *c)
     hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters); hipFree(c->d_params); hipFree(c->d_palette);
     hipFree(c->d_log); hipFree(c->d_dir);
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    hipEventDestroy(c->ev_frame0); hipEventDestroy(c->ev_last);
+    for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) { hipEventDestroy(c->ev_begin_[i]); hipEventDestroy(c->ev_end_[i]); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -232,6 +243,12 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
     HIPCHK(hipMalloc(&g->d_pals, 16 * 256 * FL_KNOTS));
     HIPCHK(hipMemcpy(g->d_prog, prog, 4 * nprog, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g->d_ops, ops, 16 * nops, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(g->d_pals, 0, 16 * 256 * FL_KNOTS));
+    g->stage_bytes = 2 * 4 * (size_t)nrows * FL_KNOTS + 16 * 256 * (FL_KNOTS - 1) + 4 * FL_KNOTS;
+    for (int i = 0; i < fl_genome::kStage; ++i) {
+        HIPCHK(hipHostMalloc((void **)&g->h_stage[i], g->stage_bytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&g->ev_stage[i], hipEventDisableTiming));
+    }
     *out = g;
     return FL_OK;
 }
@@ -241,6 +258,7 @@ void fl_genome_destroy(fl_genome *g)
     if (!g) return;
     hipFree(g->d_prog); hipFree(g->d_ops); hipFree(g->d_times); hipFree(g->d_knots);
     hipFree(g->d_ptimes); hipFree(g->d_pals);
+    for (int i = 0; i < fl_genome::kStage; ++i) { if (g->h_stage[i]) hipHostFree(g->h_stage[i]); if (g->ev_stage[i]) hipEventDestroy(g->ev_stage[i]); }
     delete g;
 }
 
@@ -249,15 +267,34 @@ int fl_genome_upload(fl_ctx *c, fl_genome *g, const float *times, const float *k
 {
     REQUIRE(c && g && times && knots && pal_rgba && pal_times, "null argument");
     REQUIRE(npal >= 1 && npal < FL_KNOTS, "bad palette count");
-    size_t nb = 4 * (size_t)g->nrows * FL_KNOTS;
-    // synchronous copies: the host arrays are ordinary (pageable) numpy memory
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(g->d_times, times, nb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->d_knots, knots, nb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(g->d_pals, 0, 16 * 256 * FL_KNOTS));
-    HIPCHK(hipMemcpy(g->d_pals, pal_rgba, 16 * 256 * (size_t)npal, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->d_ptimes, pal_times, 4 * FL_KNOTS, hipMemcpyHostToDevice));
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nb = 4 * (size_t)g->nrows * FL_KNOTS, pb = 16 * 256 * (size_t)npal, tb = 4 * FL_KNOTS;
+    const int slot = g->stage_next;
+    g->stage_next = (slot + 1) % fl_genome::kStage;
+    HIPCHK(hipEventSynchronize(g->ev_stage[slot]));        // the copy that last used this slot is done
+    unsigned char *h = g->h_stage[slot];
+    memcpy(h, times, nb);
+    memcpy(h + nb, knots, nb);
+    memcpy(h + 2 * nb, pal_rgba, pb);
+    memcpy(h + 2 * nb + pb, pal_times, tb);
+    HIPCHK(hipMemcpyAsync(g->d_times, h, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(g->d_knots, h + nb, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(g->d_pals, h + 2 * nb, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(g->d_ptimes, h + 2 * nb + pb, tb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(g->ev_stage[slot], c->stream));
     g->npal = npal;
+    return FL_OK;
+}
+
+int fl_frame_begin(fl_ctx *c, uint32_t *frame_id)
+{
+    REQUIRE(c && frame_id, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t id = c->frame_seq++;
+    const uint32_t k = id % fl_ctx::kFrames;
+    HIPCHK(hipEventRecord(c->ev_begin_[k], c->stream));
+    HIPCHK(hipEventRecord(c->ev_end_[k], c->stream));       // moved forward by fl_output
+    *frame_id = id;
     return FL_OK;
 }
 
@@ -266,9 +303,6 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     REQUIRE(c && g && g->npal, "genome not uploaded");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
-    // new frame: restart the measurement lists
-    c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
-    HIPCHK(hipEventRecord(c->ev_frame0, c->stream));
     fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * c->nw * 64;
     launch_interp_palette(c->stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, c->d_palette);
     launch_interp_params(c->stream, c->d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
@@ -297,8 +331,8 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint
 {
     const uint32_t nt = (uint32_t)c->nw * 64;
     *tiles_x = (d.astride + 127) / 128;
-    *nbins = *tiles_x * ((d.ah + 127) / 128);
-    if (*nbins > 1023) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 1023 tiles)", __FILE__, __LINE__);
+    *nbins = *tiles_x * ((d.ah + 63) / 64);
+    if (*nbins > 2047) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 2047 tiles of 128x64)", __FILE__, __LINE__);
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
     size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
@@ -469,24 +503,52 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     launch_f32_to_rgba(c->stream, d, c->d_front, c->d_rng, c->nslots * (uint32_t)c->nw * 64, fmt, dst);
     HIPCHK(hipGetLastError());
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->ev_last, c->stream));
+    if (c->frame_seq) HIPCHK(hipEventRecord(c->ev_end_[(c->frame_seq - 1) % fl_ctx::kFrames], c->stream));
     return FL_OK;
 }
 
-int fl_frame_ms(fl_ctx *c, float *ms)
+int fl_frame_ms(fl_ctx *c, uint32_t frame_id, float *ms)
 {
     REQUIRE(c && ms, "null argument");
-    HIPCHK(hipEventRecord(c->ev_last, c->stream));
-    HIPCHK(hipEventSynchronize(c->ev_last));
-    HIPCHK(hipEventElapsedTime(ms, c->ev_frame0, c->ev_last));
+    REQUIRE(frame_id < c->frame_seq && c->frame_seq - frame_id <= fl_ctx::kFrames, "frame id no longer tracked");
+    const uint32_t k = frame_id % fl_ctx::kFrames;
+    HIPCHK(hipEventSynchronize(c->ev_end_[k]));
+    HIPCHK(hipEventElapsedTime(ms, c->ev_begin_[k], c->ev_end_[k]));
     return FL_OK;
 }
+
+int fl_frame_query(fl_ctx *c, uint32_t frame_id)
+{
+    REQUIRE(c, "null ctx");
+    REQUIRE(frame_id < c->frame_seq && c->frame_seq - frame_id <= fl_ctx::kFrames, "frame id no longer tracked");
+    hipError_t e = hipEventQuery(c->ev_end_[frame_id % fl_ctx::kFrames]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(FL_E_HIP, "hipEventQuery", __FILE__, __LINE__, e);
+}
+
+void *fl_host_alloc(size_t nbytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, nbytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void fl_host_free(void *p) { if (p) hipHostFree(p); }
 
 static float sum_ms(std::vector<EvPair> &v)
 {
     float t = 0.0f;
     for (auto &p : v) { float ms = 0.0f; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) t += ms; }
     return t;
+}
+
+int fl_timings_reset(fl_ctx *c)
+{
+    REQUIRE(c, "null ctx");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
+    return FL_OK;
 }
 
 int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *nlaunch)

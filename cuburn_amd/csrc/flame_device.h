@@ -40,18 +40,23 @@ __device__ __forceinline__ void unpack_cell(u64 cell, float &y, float &u, float 
 // hot flag (0..3) -> sample weight 1, 2, 8, 32  (cuburn/code/iter.py:326)
 __device__ __forceinline__ float hot_mult(uint32_t flag) { return flag ? (float)((1u << (flag << 1)) >> 1) : 1.0f; }
 
-// ---- fast math, the forms nvcc -use_fast_math gives the reference (cuburn/code/util.py:96) ---
-__device__ __forceinline__ float fsin(float x) { return __sinf(x); }
-__device__ __forceinline__ float fcos(float x) { return __cosf(x); }
-__device__ __forceinline__ float ftan(float x) { return __fdividef(__sinf(x), __cosf(x)); }
-__device__ __forceinline__ float fexp(float x) { return __expf(x); }
-__device__ __forceinline__ float flog(float x) { return __logf(x); }
-__device__ __forceinline__ float flog2(float x) { return __log2f(x); }
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float fpow(float x, float y) { return __powf(x, y); }
-__device__ __forceinline__ float fdiv(float a, float b) { return __fdividef(a, b); }
+// ---- fast math: single hardware instructions (v_exp_f32, v_log_f32, v_rcp_f32, v_sqrt_f32,
+// v_sin_f32, v_cos_f32), the counterpart of what nvcc -use_fast_math gives the reference
+// (cuburn/code/util.py:96).  HIP's __powf/__expf/__fdividef expand to long IEEE-careful
+// sequences (a __powf is ~80 instructions, __fdividef a full div_scale/div_fmas/div_fixup);
+// these helpers do not: ~1 ulp, no denormal results, x/0 = inf, pow(0,y>0) = 0.
 __device__ __forceinline__ float frcp(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * FM_LOG2E); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718246460f; }
+__device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 __device__ __forceinline__ float fsqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+// v_sin/v_cos take revolutions; v_fract keeps the argument in the instruction's valid domain
+__device__ __forceinline__ float fsin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189532f)); }
+__device__ __forceinline__ float fcos(float x) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.15915494309189532f)); }
+__device__ __forceinline__ float ftan(float x) { return fsin(x) * frcp(fcos(x)); }
 
 // cvt.rni.s32.f32 (cuburn/code/util.py:194-200): round-to-nearest-even, saturating, NaN -> 0
 __device__ __forceinline__ uint32_t trunca(float f) {
@@ -60,6 +65,13 @@ __device__ __forceinline__ uint32_t trunca(float f) {
     if (f >= 2147483648.0f) i = 0x7fffffff;
     return (f != f) ? 0u : (uint32_t)i;                              // ... and 0 here
 }
+
+// ---- binned accumulate geometry: 128 x 64 pixel tiles; record = {bin 11 | ly 6 | lx 7 | ci 8} --------
+#define FL_TILE_W 128u
+#define FL_TILE_H 64u
+#define FL_TILE_CELLS (FL_TILE_W * FL_TILE_H)
+#define FL_REC_BITS 21u                      /* ly 6 + lx 7 + ci 8 */
+#define FL_MAX_BINS 2047u
 
 // XCD id of the executing workgroup (HW_REG_XCC_ID, bits [3:0])
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7; }

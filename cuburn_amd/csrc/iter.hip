@@ -70,12 +70,12 @@ __device__ __forceinline__ void reseed(float &x, float &y, float &c, mwc_t &r) {
     x = mwc_next_11(r); y = mwc_next_11(r); c = mwc_next_01(r);
 }
 
-// Geometry of the binned accumulate (FL_ACCUM_BINNED): the image is cut into 128x128-pixel tiles
-// ("bins"); a sample record is 22 bits {offset in tile 14, palette column 8}; a staged record
-// carries its bin number above that.
+// Geometry of the binned accumulate (FL_ACCUM_BINNED): the image is cut into 128x64-pixel tiles
+// ("bins"); a sample record is 21 bits {row in tile 6, column 7, palette column 8}; a staged
+// record carries its bin number (11 bits) above that.
 struct BinGeom {
     uint32_t tiles_x;        // tiles per row
-    uint32_t nbins;          // number of tiles B (<= 1023)
+    uint32_t nbins;          // number of tiles B (<= FL_MAX_BINS)
     uint32_t rounds;         // R: write-enabled rounds per batch
     uint32_t nbatch_total;   // batches of this launch = nslots * batches per slot
     uint32_t *log;           // [nbatch_total * R * NT] sorted records
@@ -187,8 +187,8 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         } else if (ACC == 1) {
             // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
             // and written to this slot's private region of the sample log (no global atomics)
-            const uint32_t bin = ok ? (iy >> 7) * bg.tiles_x + (ix >> 7) : bg.nbins;
-            const uint32_t rec = (bin << 22) | ((iy & 127u) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
+            const uint32_t bin = ok ? (iy >> 6) * bg.tiles_x + (ix >> 7) : bg.nbins;
+            const uint32_t rec = (bin << FL_REC_BITS) | ((iy & 63u) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (++staged == bg.rounds || rd + 1 == nrounds) {
@@ -211,8 +211,8 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                 __syncthreads();
                 for (uint32_t i = tid; i < n; i += NT) {
                     const uint32_t r2 = stage[i];
-                    const uint32_t pos = __hip_atomic_fetch_add(cur + (r2 >> 22), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    sorted[pos] = r2 & 0x3fffffu;
+                    const uint32_t pos = __hip_atomic_fetch_add(cur + (r2 >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    sorted[pos] = r2 & ((1u << FL_REC_BITS) - 1u);
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;

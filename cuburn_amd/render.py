@@ -23,20 +23,24 @@ Dimensions = namedtuple('Dimensions', 'w h aw ah astride')
 class DurationEvent(object):
     """Completion handle of one queued frame (cuburn/render.py:26-38)."""
 
-    def __init__(self, ctx):
-        self._ctx = ctx
+    def __init__(self, ctx, frame_id):
+        self._ctx, self._id = ctx, frame_id
         self._ms = None
 
     def synchronize(self):
         if self._ms is None:
             ms = C.c_float()
-            _lib.check(_lib.load().fl_frame_ms(self._ctx, C.byref(ms)))
+            _lib.check(_lib.load().fl_frame_ms(self._ctx, self._id, C.byref(ms)))
             self._ms = ms.value
         return self
 
     def query(self):
-        self.synchronize()
-        return True
+        if self._ms is not None:
+            return True
+        rc = _lib.load().fl_frame_query(self._ctx, self._id)
+        if rc < 0:
+            _lib.check(rc)
+        return rc == 1
 
     def time(self):
         """Milliseconds from the start of the frame to the end of its D2H copy."""
@@ -69,14 +73,25 @@ class Framebuffers(object):
         _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, self.nwalkers, nslots, C.byref(ctx)))
         self.ctx = ctx
         self._host = {}
+        self._pinned_ptrs = []
+
+    def _pinned(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _lib.load().fl_host_alloc(n)
+        if not p:
+            raise MemoryError('pinned host allocation of %d bytes failed' % n)
+        self._pinned_ptrs.append(p)
+        buf = (C.c_ubyte * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def host_buffer(self, shape, dtype):
+        """Page-locked output buffers, rotated so that up to three frames may be in flight."""
         key = (tuple(shape), dtype)
         if key not in self._host:
-            self._host[key] = [np.empty(shape, dtype), np.empty(shape, dtype)]
-        pair = self._host[key]
-        pair.reverse()                      # at most two frames in flight (render.py:432-433)
-        return pair[0]
+            self._host[key] = [self._pinned(shape, dtype) for _ in range(3)]
+        ring = self._host[key]
+        ring.append(ring.pop(0))
+        return ring[-1]
 
     def set_dim(self, width, height, stream=None):
         return self.calc_dim(width, height)
@@ -93,6 +108,11 @@ class Framebuffers(object):
 
     def free(self):
         if self.ctx:
+            _lib.load().fl_ctx_sync(self.ctx)
+            self._host.clear()
+            for p in self._pinned_ptrs:
+                _lib.load().fl_host_free(p)
+            self._pinned_ptrs = []
             _lib.load().fl_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -141,8 +161,8 @@ class Renderer(object):
 class RenderManager(object):
     """Frame queue (cuburn/render.py:253-434)."""
 
-    # 'auto': binned accumulate (sample log + LDS tiles) whenever the image has <= 1023 tiles of
-    # 128x128 pixels (up to 4K), else direct packed global atomics.  Both give the same histogram.
+    # 'auto': binned accumulate (sample log + LDS tiles) whenever the image has <= 2047 tiles of
+    # 128x64 pixels (up to 4K), else direct packed global atomics.  Both give the same histogram.
     accum_mode = 'auto'
     fuse = 256                      # write-disabled iterations per walker per frame (render.py:215)
 
@@ -173,6 +193,8 @@ class RenderManager(object):
         td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
         ts = tc - 0.5 * td
         g = rdr._handle(self.fb)
+        fid = C.c_uint32()
+        _lib.check(lib.fl_frame_begin(self.fb.ctx, C.byref(fid)))
         if copy:
             self._copy(rdr, gnm)
         _lib.check(lib.fl_interp(self.fb.ctx, g, dim.w, dim.h, ts, td))
@@ -180,8 +202,8 @@ class RenderManager(object):
         run = C.c_uint64()
         mode = self.accum_mode
         if mode == 'auto':
-            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 127) // 128)
-            mode = _lib.ACCUM_BINNED if ntiles <= 1023 else _lib.ACCUM_ATOMIC
+            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
+            mode = _lib.ACCUM_BINNED if ntiles <= 2047 else _lib.ACCUM_ATOMIC
         _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse, mode, C.byref(run)))
         self.last_nsamples = run.value
         for filt in rdr.filts:
@@ -189,10 +211,13 @@ class RenderManager(object):
             filt.apply(self.fb, gprof, params, dim, tc)
         rdr.out.convert(self.fb, gprof, dim)
         h_out = rdr.out.copy(self.fb, dim)
-        return DurationEvent(self.fb.ctx), h_out
+        return DurationEvent(self.fb.ctx, fid.value), h_out
+
+    def timings_reset(self):
+        _lib.check(_lib.load().fl_timings_reset(self.fb.ctx))
 
     def timings(self):
-        """HIP-event times (ms) of the last frame's iterate, flush and filter kernels."""
+        """HIP-event times (ms) of the iterate, drain and filter kernels since timings_reset()."""
         it, fl, ft, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
         _lib.check(_lib.load().fl_timings(self.fb.ctx, C.byref(it), C.byref(fl), C.byref(ft), C.byref(n)))
         return dict(iter_ms=it.value, flush_ms=fl.value, filter_ms=ft.value, launches=n.value)

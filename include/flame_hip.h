@@ -187,12 +187,23 @@ int fl_filter(fl_ctx *ctx, int filter_id, uint32_t w, uint32_t h, const float *p
  * when dev_out != 0). fmt: 0 = u8 x4, 1 = u16 x4. */
 int fl_output(fl_ctx *ctx, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out);
 
-/* cuburn/render.py:26-38 DurationEvent: ms from the start of the current frame
- * (first fl_interp) to the last queued op; blocks until done. */
-int fl_frame_ms(fl_ctx *ctx, float *ms);
+/* cuburn/render.py:404,430 timing_event / DurationEvent: fl_frame_begin opens a frame and returns
+ * its id; fl_output closes it.  fl_frame_ms blocks until that frame is done and gives the ms
+ * between the two (DurationEvent.time, render.py:26-38); fl_frame_query is DurationEvent.query
+ * (1 done, 0 running).  Up to 4 frames may be in flight. */
+int fl_frame_begin(fl_ctx *ctx, uint32_t *frame_id);
+int fl_frame_ms(fl_ctx *ctx, uint32_t frame_id, float *ms);
+int fl_frame_query(fl_ctx *ctx, uint32_t frame_id);
+
+/* cuburn/render.py:93 PageLockedMemoryPool: pinned host memory for h_out so that the D2H copy of
+ * fl_output is truly asynchronous. */
+void *fl_host_alloc(size_t nbytes);
+void fl_host_free(void *p);
 
 /* ---- measurement taps (bench.py / tests only) ---- */
-/* HIP-event time of the iterate+flush kernels and of the filter kernels of the last frame. */
+/* HIP-event times accumulated since the last fl_timings_reset: iterate kernels; drain kernels
+ * (tile accumulate + flush); filter kernels; number of iterate launches.  Both calls sync. */
+int fl_timings_reset(fl_ctx *ctx);
 int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *niter_launches);
 
 /* ---- debug taps (tests only): read/write device state ---- */

@@ -390,8 +390,11 @@ def test_queue_frame_end_to_end(mgr):
     gnm, prof = small(configs.cfg3, 320, 180, samples=2 ** 24)
     gprof = profile.wrap(prof, gnm)
     rdr = render.Renderer(gnm, gprof)
+    mgr.timings_reset()
     evt, h_out = mgr.queue_frame(rdr, gnm, gprof, 0.25)
+    assert evt.query() in (True, False)
     evt.synchronize()
+    assert evt.query() is True
     assert evt.time() > 0
     assert h_out.shape == (180, 320, 4) and h_out.dtype == np.uint8
     assert h_out[..., 3].max() > 100 and (h_out[..., :3].max() > 50)
