@@ -85,7 +85,7 @@ def main():
     from cuburn_amd import configs, profile, render, _lib
     gnm, prof = configs.CONFIGS[args.config]()
     gprof = profile.wrap(prof, gnm)
-    mgr = render.RenderManager(device=local, nslots=1024, host_seed=42 + rank)
+    mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1024)), host_seed=42 + rank)
     mgr.accum_mode = _lib.ACCUM_BINNED if args.accum == 'binned' else _lib.ACCUM_ATOMIC
     rdr = render.Renderer(gnm, gprof)
     w, h = gprof.width, gprof.height

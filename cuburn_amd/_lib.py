@@ -53,6 +53,7 @@ _SIGS = {
     'fl_debug_clear_hot': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     'fl_debug_shuffle': (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     'fl_debug_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'fl_debug_apply_xf': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -83,7 +83,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
                 rec[k] = live[k] ? log[(size_t)rbatch * batch_records + r_first + (v - r_excl)] : 0u;
-                row[k] = ((rbatch % nslots) & (FL_NTEMPORAL - 1)) >> 4;
+                row[k] = ((rbatch % nslots) % FL_NTEMPORAL) >> 4;
             }
             u64 val[ACC_ILP];
 #pragma unroll

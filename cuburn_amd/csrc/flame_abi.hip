@@ -138,7 +138,7 @@ static int ensure_fb(fl_ctx *c, const fl_dim &d)
 int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out)
 {
     REQUIRE(out && seeds, "null argument");
-    REQUIRE(nslots >= FL_NTEMPORAL && (nslots & (nslots - 1)) == 0, "nslots must be a power of two >= 1024");
+    REQUIRE(nslots >= FL_NTEMPORAL && nslots % 256 == 0 && nslots <= 16384, "nslots must be a multiple of 256 in [1024, 16384]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FL_E_NODEV, "no HIP device", __FILE__, __LINE__);
     REQUIRE(device >= 0 && device < ndev, "bad device index");
@@ -190,32 +190,25 @@ void fl_ctx_destroy(fl_ctx *c)
 
 int fl_ctx_sync(fl_ctx *c) { REQUIRE(c, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return FL_OK; }
 
-// Validate the xform program before any kernel trusts it (the reference traps on device,
-// cuburn/code/iter.py:254-257).
+// Validate the program header before any kernel trusts it (the reference traps on device,
+// cuburn/code/iter.py:254-257).  Variation numbers live in the parameter block as FL_OP_CONST
+// ops and are checked with the op list.
 static int check_prog(const int32_t *p, uint32_t n)
 {
-    REQUIRE(n >= FL_PROG_HDR + 1 && p[0] == FL_PROG_MAGIC, "bad program header");
-    int nxf = p[1], hf = p[2], ps = p[3], cdf = p[4];
+    REQUIRE(n >= FL_PROG_HDR && p[0] == FL_PROG_MAGIC, "bad program header");
+    int nxf = p[1], hf = p[2], ps = p[3], cdf = p[4], xo = p[5], xs = p[6], vs = p[7];
     REQUIRE(nxf >= 1 && nxf <= FL_MAX_XFORMS && (hf == 0 || hf == 1), "bad xform count");
     REQUIRE(ps >= 6 + nxf && ps <= FL_MAX_PSTRIDE, "bad pstride");
-    REQUIRE(cdf >= 6 && cdf + nxf <= ps, "bad cdf offset");
-    REQUIRE(n >= (uint32_t)(FL_PROG_HDR + nxf + hf), "truncated descriptor table");
-    for (int i = 0; i < nxf + hf; ++i) {
-        int off = p[FL_PROG_HDR + i];
-        REQUIRE(off >= FL_PROG_HDR + nxf + hf && (uint32_t)off + 3 <= n, "descriptor offset out of range");
-        const int32_t *d = p + off;
-        int rec = 8 + ((d[1] & 1) ? 6 : 0);
-        REQUIRE(d[0] >= 6 && d[0] + rec <= ps, "xform record out of range");
-        REQUIRE(d[2] >= 0 && (uint32_t)off + 3 + 2 * (uint32_t)d[2] <= n, "variation list out of range");
-        for (int j = 0; j < d[2]; ++j) {
-            int id = d[3 + 2 * j], vo = d[4 + 2 * j];
-            bool known = false;
-            for (int k : kKnownVars) known |= (k == id);
-            if (!known) return fail(FL_E_UNSUPPORTED, "unknown variation id", __FILE__, __LINE__);
-            REQUIRE(vo >= 6 && vo + 9 <= ps + 8 && vo < ps, "variation record out of range");
-        }
-    }
+    REQUIRE(cdf >= 6 && cdf + nxf <= xo, "bad cdf offset");
+    REQUIRE(xs >= FL_XF_HDR + vs && (xs % 4) == 0 && vs >= 2 && vs <= 64, "bad record strides");
+    REQUIRE(xo + (nxf + hf) * xs <= ps, "xform records exceed the block");
     return FL_OK;
+}
+
+static bool known_var(int id)
+{
+    for (int k : kKnownVars) if (k == id) return true;
+    return false;
 }
 
 int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops,
@@ -226,11 +219,27 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
     if (rc) return rc;
     REQUIRE(nrows >= 1 && nrows <= 4096 && nops >= 1, "bad row / op count");
     uint32_t ps = prog[3];
+    const int xo = prog[5], xs = prog[6], vs = prog[7], nrec = prog[1] + prog[2];
+    std::vector<int> nvar_seen(nrec, -1);
     for (uint32_t i = 0; i < nops; ++i) {
         const int32_t *o = ops + 4 * i;
-        REQUIRE(o[0] >= FL_OP_SPLINE && o[0] <= FL_OP_INVSQ_MAX, "bad op kind");
-        REQUIRE(o[1] >= 0 && (uint32_t)o[1] < ps && o[2] >= 0 && (uint32_t)o[2] < nrows, "op out of range");
+        REQUIRE(o[0] >= FL_OP_SPLINE && o[0] <= FL_OP_CONST, "bad op kind");
+        REQUIRE(o[1] >= 0 && (uint32_t)o[1] < ps, "op destination out of range");
+        if (o[0] != FL_OP_CONST) { REQUIRE(o[2] >= 0 && (uint32_t)o[2] < nrows, "op row out of range"); continue; }
+        // structure words: xform word 14 (nvar | post << 8) or a variation number
+        const int rel = o[1] - xo;
+        REQUIRE(rel >= 0 && rel / xs < nrec, "structure word outside the xform records");
+        const int w = rel % xs;
+        if (w == 14) {
+            const int nv = o[2] & 0xff;
+            REQUIRE(FL_XF_HDR + nv * vs <= xs && (o[2] >> 9) == 0, "bad variation count");
+            nvar_seen[rel / xs] = nv;
+        } else {
+            REQUIRE(w >= FL_XF_HDR && (w - FL_XF_HDR) % vs == 0, "misplaced structure word");
+            if (!known_var(o[2])) return fail(FL_E_UNSUPPORTED, "unknown variation id", __FILE__, __LINE__);
+        }
     }
+    for (int i = 0; i < nrec; ++i) REQUIRE(nvar_seen[i] >= 0, "xform record without a variation count");
     HIPCHK(hipSetDevice(c->device));
     fl_genome *g = new fl_genome;
     g->prog.assign(prog, prog + nprog);
@@ -654,6 +663,24 @@ int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out256, d, 4 * n, hipMemcpyDeviceToHost));
     hipFree(d);
+    return FL_OK;
+}
+
+int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng)
+{
+    REQUIRE(c && g && xyzw && rng && n > 0 && ts < FL_NTEMPORAL, "bad argument");
+    REQUIRE(xfi >= 0 && xfi < g->prog[1] + g->prog[2], "xform index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    float4 *dp; fl_mwc *dr;
+    HIPCHK(hipMalloc(&dp, 16 * (size_t)n));
+    HIPCHK(hipMalloc(&dr, sizeof(fl_mwc) * (size_t)n));
+    HIPCHK(hipMemcpy(dp, xyzw, 16 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr, rng, sizeof(fl_mwc) * (size_t)n, hipMemcpyHostToDevice));
+    launch_apply_xf_tap(c->stream, g->d_prog, c->d_params, ts, xfi, n, dp, dr);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(xyzw, dp, 16 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rng, dr, sizeof(fl_mwc) * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(dp); hipFree(dr);
     return FL_OK;
 }
 

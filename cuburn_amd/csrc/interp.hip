@@ -67,6 +67,7 @@ k_interp_params(float *__restrict__ params, const float *__restrict__ times, con
     if (id >= FL_NTEMPORAL) return;
     const float time = tstart + (float)id * tstep;
     float *out = params + (size_t)id * pstride;
+    for (uint32_t i = 0; i < pstride; ++i) out[i] = 0.0f;          // padding / unused post affines
 #define ROW(r, mag) catmull_rom(times + (size_t)(r) * FL_KNOTS, knots + (size_t)(r) * FL_KNOTS, time, mag)
     for (uint32_t i = 0; i < nops; ++i) {
         const int4 op = ops[i];
@@ -113,6 +114,7 @@ k_interp_params(float *__restrict__ params, const float *__restrict__ times, con
             float pdist = fmaxf(1e-9f, ROW(op.w, true));
             o[0] = pdist; o[1] = sinf(pang); o[2] = pdist * cosf(pang);
         } break;
+        case FL_OP_CONST: o[0] = __int_as_float(op.z); break;
         default: break;
         }
     }

@@ -21,27 +21,26 @@ __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_
 }
 
 // cuburn/code/iter.py:121-149: pre affine, sum of variations, optional post affine, colour
-// blend.  `xfi` is wave-uniform; all prog[] / P[] reads are scalar.
-__device__ __forceinline__ void apply_xf(const int32_t *__restrict__ prog, const float *__restrict__ P,
+// blend.  `xfi` is wave-uniform; the record address is plain arithmetic on it (fixed strides,
+// include/flame_hip.h (5)), so every read below is an s_load with no pointer chasing.
+__device__ __forceinline__ void apply_xf(const float *__restrict__ P, int xf_off, int xf_stride, int var_stride,
                                          int xfi, float &x, float &y, float &c, mwc_t &r)
 {
-    const int32_t *d = prog + prog[FL_PROG_HDR + xfi];
-    const float *xf = P + d[0];
-    const int nvar = d[2];
+    const float *__restrict__ xf = P + xf_off + xfi * xf_stride;
+    const int word14 = __float_as_int(xf[14]);
+    const int nvar = word14 & 0xff;
     float tx = fmaf(xf[0], x, fmaf(xf[1], y, xf[2]));
     float ty = fmaf(xf[3], x, fmaf(xf[4], y, xf[5]));
     float ox = 0.0f, oy = 0.0f;
     for (int j = 0; j < nvar; ++j)
-        apply_variation(d[3 + 2 * j], P + d[4 + 2 * j], xf, tx, ty, ox, oy, r);
-    const float *cp = xf + 6;
-    if (d[1] & 1) {
-        float qx = fmaf(cp[0], ox, fmaf(cp[1], oy, cp[2]));
-        float qy = fmaf(cp[3], ox, fmaf(cp[4], oy, cp[5]));
+        apply_variation(xf + FL_XF_HDR + j * var_stride, xf, tx, ty, ox, oy, r);
+    if (word14 & 0x100) {
+        const float qx = fmaf(xf[6], ox, fmaf(xf[7], oy, xf[8]));
+        const float qy = fmaf(xf[9], ox, fmaf(xf[10], oy, xf[11]));
         ox = qx; oy = qy;
-        cp = xf + 12;
     }
-    const float csp = cp[1];
-    c = fmaf(c, 1.0f - csp, cp[0] * csp);
+    const float csp = xf[13];
+    c = fmaf(c, 1.0f - csp, xf[12] * csp);
     x = ox; y = oy;
 }
 
@@ -113,8 +112,9 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const uint32_t slot = blockIdx.x, ts = slot & (FL_NTEMPORAL - 1);
+    const uint32_t slot = blockIdx.x, ts = slot % FL_NTEMPORAL;
     const int nxf = prog[1], has_final = prog[2], pstride = prog[3], cdf_off = prog[4];
+    const int xf_off = prog[5], xf_stride = prog[6], var_stride = prog[7];
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
     if (ACC != 1) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
@@ -131,6 +131,12 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     __syncthreads();
 
     uint32_t phase = round0 % 3u;
+    // cumulative xform densities of this slot's temporal sample: constant for the whole launch
+    float cdf[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cdf[i] = (i < nxf - 1) ? P[cdf_off + i] : 2.0f;
+    const float fa_stride = (float)astride - 0.5f, fa_height = (float)aheight - 0.5f;
+    const uint32_t dst0 = shuffle_dest<NW>(w, l, 0), dst1 = shuffle_dest<NW>(w, l, 1), dst2 = shuffle_dest<NW>(w, l, 2);
     uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
     bool pend_ok = false; uint32_t pend_gi = 0; float pend_mult = 1.0f; u64 pend_old = 0;
 
@@ -140,13 +146,22 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         // wave-coherent xform choice: lane 0's draw (iter.py:260-272 uses a shared cosel[])
         const uint32_t sel = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
         const float xfsel = (float)sel * (1.0f / 4294967296.0f);
-        int k = nxf - 1;
-        for (int i = nxf - 2; i >= 0; --i) if (xfsel <= P[cdf_off + i]) k = i;
-        apply_xf(prog, P, k, x, y, color, rctx);
+        int k;
+        if (nxf <= 8) {
+            k = 7;
+#pragma unroll
+            for (int i = 6; i >= 0; --i) if (xfsel <= cdf[i]) k = i;
+            k = min(k, nxf - 1);
+        } else {
+            k = nxf - 1;
+            for (int i = nxf - 2; i >= 0; --i) if (xfsel <= P[cdf_off + i]) k = i;
+        }
+        k = __builtin_amdgcn_readfirstlane(k);
+        apply_xf(P, xf_off, xf_stride, var_stride, k, x, y, color, rctx);
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
-            const uint32_t par = rd & 1u, dst = shuffle_dest<NW>(w, l, phase);
+            const uint32_t par = rd & 1u, dst = phase == 0 ? dst0 : (phase == 1 ? dst1 : dst2);
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
@@ -155,11 +170,15 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         if (rd < fuse) continue;                                            // iter.py:298-300
 
         float fx = x, fy = y, fc = color;
-        if (has_final) apply_xf(prog, P, nxf, fx, fy, fc, rctx);            // iter.py:302-307
+        if (has_final) apply_xf(P, xf_off, xf_stride, var_stride, nxf, fx, fy, fc, rctx);   // iter.py:302-307
         const float cx = fmaf(P[0], fx, fmaf(P[1], fy, P[2]));              // iter.py:306-309
         const float cy = fmaf(P[3], fx, fmaf(P[4], fy, P[5]));
-        const uint32_t ix = trunca(cx), iy = trunca(cy);                    // iter.py:313
-        bool ok = ix < astride && iy < aheight;                             // iter.py:315-317
+        // iter.py:313-317: round to nearest even, reject outside [0, astride) x [0, aheight).
+        // Done in the float domain (both limits are even, so x.5 ties round outward at the top
+        // and to 0 at the bottom): one compare chain instead of two saturating conversions.
+        bool ok = cx >= -0.5f && cx < fa_stride && cy >= -0.5f && cy < fa_height;     // NaN -> false
+        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok ? cx : 0.0f);
+        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok ? cy : 0.0f);
         if (COUNT) n_oob += !ok;
         const uint32_t gi = ok ? iy * astride + ix : 0u;
 
@@ -240,6 +259,28 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         atomicAdd(counters + 2, (u64)n_drop);
         atomicAdd(counters + 3, (u64)n_spill);
     }
+}
+
+// Xform tap: apply xform `xfi` of temporal sample `ts` once to n independent points (one per
+// thread, own RNG state).  For the per-variation parity tests.
+__global__ void __launch_bounds__(256)
+k_apply_xf_tap(const int32_t *__restrict__ prog, const float *__restrict__ params, uint32_t ts, int xfi,
+               uint32_t n, float4 *__restrict__ pts, fl_mwc *__restrict__ rng)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float *__restrict__ P = params + (size_t)ts * prog[3];
+    mwc_t r = {rng[i].mul, rng[i].state, rng[i].carry};
+    float4 p = pts[i];
+    apply_xf(P, prog[5], prog[6], prog[7], xfi, p.x, p.y, p.z, r);
+    pts[i] = p;
+    rng[i].mul = r.mul; rng[i].state = r.state; rng[i].carry = r.carry;
+}
+
+void launch_apply_xf_tap(hipStream_t st, const int32_t *prog, const float *params, uint32_t ts, int xfi,
+                         uint32_t n, float4 *pts, fl_mwc *rng)
+{
+    hipLaunchKernelGGL(k_apply_xf_tap, dim3((n + 255) / 256), dim3(256), 0, st, prog, params, ts, xfi, n, pts, rng);
 }
 
 // Point-shuffle tap: one swap of the identity payload, for the bit-exact permutation test.

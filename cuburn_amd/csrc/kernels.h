@@ -15,6 +15,8 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  uint32_t *log, uint32_t *dir);
 void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot);
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
+void launch_apply_xf_tap(hipStream_t st, const int32_t *prog, const float *params, uint32_t ts, int xfi,
+                         uint32_t n, float4 *pts, fl_mwc *rng);
 
 // binned.hip
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,

@@ -9,8 +9,8 @@
 #pragma once
 #include "flame_device.h"
 
-#define VW (v[0])
-#define VP(i) (v[1 + (i)])
+#define VW (w)
+#define VP(i) (v[(i)])
 #define OUT(a, b) do { ox += (a); oy += (b); } while (0)
 
 __device__ __forceinline__ float v_atan2(float a, float b) { return atan2f(a, b); }
@@ -19,10 +19,16 @@ __device__ __forceinline__ float v_gauss_r(float w, mwc_t &r) {
     return w * 0.57736f * fsqrt(fdiv(-2.0f * flog2(mwc_next_01(r)), FM_LOG2E));
 }
 
-// Returns false for an unknown id (host rejects such programs up front).
-__device__ __forceinline__ bool apply_variation(int id, const float *__restrict__ v,
-                                                const float *__restrict__ xf,
-                                                float &tx, float &ty, float &ox, float &oy, mwc_t &r)
+// The 16 cheapest / most common variations (flam3 numbers 0..15 minus the two that need
+// invariants hoisted) are dispatched inline; everything else goes through ONE out-of-line
+// function.  Keeping the big switch out of the iteration loop matters on AMDGPU: LLVM hoists
+// loop-invariant pieces of *every* case (e.g. the fmod set-up of `rings`) into the loop
+// preheader, where they would run on every round whatever the variation.
+struct VarIO { float tx, ty, ox, oy; uint32_t state, carry; };
+
+__device__ __forceinline__ bool apply_variation_body(int id, float w, const float *__restrict__ v,
+                                                     const float *__restrict__ xf,
+                                                     float &tx, float &ty, float &ox, float &oy, mwc_t &r)
 {
     const float r2 = fmaf(tx, tx, ty * ty);
     switch (id) {
@@ -302,6 +308,40 @@ __device__ __forceinline__ bool apply_variation(int id, const float *__restrict_
     default: return false;
     }
     return true;
+}
+
+__device__ __noinline__ VarIO apply_variation_slow(int id, float w, const float *__restrict__ v,
+                                                   const float *__restrict__ xf, VarIO io, uint32_t mul)
+{
+    mwc_t r = {mul, io.state, io.carry};
+    apply_variation_body(id, w, v, xf, io.tx, io.ty, io.ox, io.oy, r);
+    io.state = r.state; io.carry = r.carry;
+    return io;
+}
+
+// v points at the variation record {id, weight, params...} (include/flame_hip.h (5)).
+__device__ __forceinline__ void apply_variation(const float *__restrict__ v, const float *__restrict__ xf,
+                                                float &tx, float &ty, float &ox, float &oy, mwc_t &r)
+{
+    const int id = __float_as_int(v[0]);
+    const float w = v[1];
+    const float r2 = fmaf(tx, tx, ty * ty);
+    if (id == 0) { OUT(tx * VW, ty * VW); }                                             // linear
+    else if (id == 2) { float k = fdiv(VW, r2); OUT(tx * k, ty * k); }                  // spherical
+    else if (id == 3) { float s = fsin(r2), c = fcos(r2);                               // swirl
+                        OUT(VW * (s * tx - c * ty), VW * (c * tx + s * ty)); }
+    else if (id == 1) { OUT(VW * fsin(tx), VW * fsin(ty)); }                            // sinusoidal
+    else if (id == 4) { float k = fdiv(VW, fsqrt(r2));                                  // horseshoe
+                        OUT(k * (tx - ty) * (tx + ty), 2.0f * tx * ty * k); }
+    else if (id == 27) { float k = fdiv(2.0f * VW, fsqrt(r2) + 1.0f); OUT(k * tx, k * ty); }   // eyefish
+    else if (id == 28) { float k = fdiv(VW, 0.25f * r2 + 1.0f); OUT(k * tx, k * ty); }  // bubble
+    else if (id == 14) { float nx = tx < 0.0f ? 2.0f : 1.0f, ny = ty < 0.0f ? 0.5f : 1.0f;   // bent
+                         OUT(VW * nx * tx, VW * ny * ty); }
+    else {
+        VarIO io = {tx, ty, ox, oy, r.state, r.carry};
+        io = apply_variation_slow(id, w, v + 2, xf, io, r.mul);
+        tx = io.tx; ty = io.ty; ox = io.ox; oy = io.oy; r.state = io.state; r.carry = io.carry;
+    }
 }
 #undef VW
 #undef VP

@@ -11,8 +11,9 @@ libflame_hip (formats: include/flame_hip.h (4)-(6)):
   * rows      one spline (32 knot times + 32 knot values) per genome parameter,
               filled per frame by ``pack`` exactly as GenomePacker.pack (interp.py:207-232).
 
-``packed`` lists the path of every float of the parameter block, in block order, like the
-reference's ``packer.packed``.
+``packed`` lists the path of every word of the parameter block, in block order, like the
+reference's ``packer.packed`` (plus ``pad`` entries for alignment and ``#id`` / ``#nvar``
+entries for the integer structure words the fixed-stride layout carries).
 """
 import numpy as np
 
@@ -22,9 +23,10 @@ from .genome.util import resolve_spec
 from .genome import variations as V
 
 KNOTS = 32          # 1 << DEFAULT_SEARCH_ROUNDS, cuburn/code/util.py:235
-PROG_MAGIC = 0x464c5031
-OP_SPLINE, OP_SPLINE_MAG, OP_CAMERA, OP_AFFINE, OP_CDF, OP_RATIO2, OP_INVSQ, OP_PERSP, OP_INVSQ_MAX = range(9)
-MAX_PSTRIDE = 1024
+PROG_MAGIC = 0x464c5032
+OP_SPLINE, OP_SPLINE_MAG, OP_CAMERA, OP_AFFINE, OP_CDF, OP_RATIO2, OP_INVSQ, OP_PERSP, OP_INVSQ_MAX, OP_CONST = range(10)
+MAX_PSTRIDE = 4096
+XF_HDR = 16
 
 _AFFINE_ROWS = (('angle',), ('spread',), ('magnitude', 'x'), ('magnitude', 'y'), ('offset', 'x'), ('offset', 'y'))
 _AFFINE_OUT = ('xx', 'xy', 'xo', 'yx', 'yy', 'yo')
@@ -35,7 +37,7 @@ class GenomePacker(object):
     def __init__(self, gnm):
         self.rows = []      # [(path, is_mag)]
         self.ops = []       # [(kind, dst, a, b)]
-        self.packed = []    # [path] per block float
+        self.packed = []    # [path] per block word ('pad' = unused, '#...' = integer structure word)
         self._row_index = {}
         self._build(gnm)
         self.genome = [p for p, _ in self.rows]
@@ -70,45 +72,47 @@ class GenomePacker(object):
             self._row_index.setdefault(path, len(self.rows) - 1)
         return first
 
-    def _alloc(self, names):
-        off = len(self.packed)
-        self.packed.extend(tuple(n) for n in names)
-        return off
-
     def _spline_op(self, dst, path):
         r = self._row(path)
         self.ops.append((OP_SPLINE_MAG if self.rows[r][1] else OP_SPLINE, dst, r, 0))
 
-    def _affine(self, base):
-        dst = self._alloc(base + (o,) for o in _AFFINE_OUT)
+    def _affine(self, base, dst):
+        for i, o in enumerate(_AFFINE_OUT):
+            self.packed[dst + i] = tuple(base) + (o,)
         first = self._new_rows(base, _AFFINE_ROWS)
         self.ops.append((OP_AFFINE, dst, first, 0))
-        return dst, first
+        return first
 
-    def _xform(self, base, xf):
-        poff, pre_rows = self._affine(base + ('pre_affine',))
-        flags = 0
-        if 'post_affine' in xf:
-            flags |= 1
-            self._affine(base + ('post_affine',))
-        c = self._alloc([base + ('color',), base + ('color_speed',)])
-        self._spline_op(c, base + ('color',))
-        self._spline_op(c + 1, base + ('color_speed',))
-        desc = [poff, flags, 0]
-        for vname in sorted(xf.get('variations', {})):
-            if vname not in V.var_ids:
-                raise ValueError('unknown variation %r' % vname)
+    def _xform(self, base, xf, rec):
+        """Fill the fixed-stride record starting at block offset ``rec`` (include/flame_hip.h (5))."""
+        pre_rows = self._affine(base + ('pre_affine',), rec)
+        has_post = 1 if 'post_affine' in xf else 0
+        if has_post:
+            self._affine(base + ('post_affine',), rec + 6)
+        self.packed[rec + 12] = base + ('color',)
+        self.packed[rec + 13] = base + ('color_speed',)
+        self._spline_op(rec + 12, base + ('color',))
+        self._spline_op(rec + 13, base + ('color_speed',))
+        names = sorted(xf.get('variations', {}))
+        self.packed[rec + 14] = base + ('#nvar',)
+        self.ops.append((OP_CONST, rec + 14, len(names) | (has_post << 8), 0))
+        for j, vname in enumerate(names):
             vbase = base + ('variations', vname)
+            voff = rec + XF_HDR + j * self.var_stride
             layout = V.record_layout(vname)
-            voff = self._alloc([vbase + ('weight',)] + [vbase + (n,) for n in layout])
-            self._spline_op(voff, vbase + ('weight',))
+            self.packed[voff] = vbase + ('#id',)
+            self.ops.append((OP_CONST, voff, V.var_ids[vname], 0))
+            self.packed[voff + 1] = vbase + ('weight',)
+            self._spline_op(voff + 1, vbase + ('weight',))
+            for i, n in enumerate(layout):
+                self.packed[voff + 2 + i] = vbase + (n,)
             direct = sorted(k for k in V.var_params[vname] if k != 'weight')
             for i, pname in enumerate(direct):
-                self._spline_op(voff + 1 + i, vbase + (pname,))
-            dst = voff + 1 + len(direct)
+                self._spline_op(voff + 2 + i, vbase + (pname,))
+            dst = voff + 2 + len(direct)
             for pname, kind, src in V.var_precalc.get(vname, ()):
                 if kind == 'invsq':      # source lives on the xform's pre affine
-                    r = pre_rows + [tuple(s) for s in _AFFINE_ROWS].index(tuple(src.split('.')[1:]))
+                    r = pre_rows + [tuple(x) for x in _AFFINE_ROWS].index(tuple(src.split('.')[1:]))
                     self.ops.append((OP_INVSQ, dst, r, 0)); dst += 1
                 elif kind == 'invsq_max':
                     self.ops.append((OP_INVSQ_MAX, dst, self._row(vbase + (src,)), 0)); dst += 1
@@ -116,9 +120,6 @@ class GenomePacker(object):
                     self.ops.append((OP_RATIO2, dst, self._row(vbase + (src[0],)), self._row(vbase + (src[1],)))); dst += 1
                 elif kind == 'persp':
                     self.ops.append((OP_PERSP, dst, self._row(vbase + (src[0],)), self._row(vbase + (src[1],)))); dst += 3
-            desc[2] += 1
-            desc.extend([V.var_ids[vname], voff])
-        return desc
 
     def _build(self, gnm):
         xforms = gnm.get('xforms', {})
@@ -127,27 +128,35 @@ class GenomePacker(object):
             raise ValueError('genome has no xforms')
         has_final = 1 if 'final_xform' in gnm else 0
         self.xform_keys = keys
+        allxf = [(('xforms', k), xforms[k]) for k in keys]
+        if has_final:
+            allxf.append((('final_xform',), gnm['final_xform']))
+        for _, xf in allxf:
+            for vname in xf.get('variations', {}):
+                if vname not in V.var_ids:
+                    raise ValueError('unknown variation %r' % vname)
+        # strides: every xform record and every variation record has the same length
+        maxv = max([len(xf.get('variations', {})) for _, xf in allxf] + [1])
+        maxp = max([len(V.record_layout(v)) for _, xf in allxf for v in xf.get('variations', {})] + [0])
+        self.var_stride = 2 + maxp
+        self.xf_stride = (XF_HDR + maxv * self.var_stride + 3) // 4 * 4
+        cdf = 6
+        self.xf_off = (cdf + len(keys) + 3) // 4 * 4
+        total = self.xf_off + len(allxf) * self.xf_stride
+        self.packed = [('pad', str(i)) for i in range(total)]
         # camera
-        cam = self._alloc(('camera', o) for o in _AFFINE_OUT)
+        for i, o in enumerate(_AFFINE_OUT):
+            self.packed[i] = ('camera', o)
         first = self._new_rows(('camera',), _CAMERA_ROWS)
-        self.ops.append((OP_CAMERA, cam, first, 0))
+        self.ops.append((OP_CAMERA, 0, first, 0))
         # cumulative xform densities
-        cdf = self._alloc(('den', k) for k in keys)
+        for i, k in enumerate(keys):
+            self.packed[cdf + i] = ('den', k)
         first = self._new_rows((), [('xforms', k, 'weight') for k in keys])
         self.ops.append((OP_CDF, cdf, first, len(keys)))
-        descs = [self._xform(('xforms', k), xforms[k]) for k in keys]
-        if has_final:
-            descs.append(self._xform(('final_xform',), gnm['final_xform']))
-        prog = [PROG_MAGIC, len(keys), has_final, 0, cdf, 0, 0, 0]
-        off = len(prog) + len(descs)
-        table = []
-        for d in descs:
-            table.append(off)
-            off += len(d)
-        prog.extend(table)
-        for d in descs:
-            prog.extend(d)
-        self._prog = prog
+        for i, (base, xf) in enumerate(allxf):
+            self._xform(base, xf, self.xf_off + i * self.xf_stride)
+        self._prog = [PROG_MAGIC, len(keys), has_final, 0, cdf, self.xf_off, self.xf_stride, self.var_stride]
 
     # ------------------------------------------------------------------ per-frame data
     def pack(self, gnm, pool=None):

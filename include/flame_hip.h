@@ -63,10 +63,13 @@ typedef struct fl_mwc {
 #define FL_PAL_H 64
 #define FL_GUTTER 12        /* cuburn/render.py:77 */
 
-/* (5) Xform program (int32 words) — replaces the per-genome generated CUDA of
- *     cuburn/code/iter.py:121-149,559-575 with a data description interpreted by one
- *     precompiled kernel.  All offsets are in 32-bit words.
+/* (5) Xform program + parameter block — replaces the per-genome generated CUDA of
+ *     cuburn/code/iter.py:121-149,559-575 with data interpreted by one precompiled kernel.
+ *     The genome's STRUCTURE (which variations, post affines, final xform) is laid out in the
+ *     parameter block itself with fixed strides, so that the kernel reaches everything about
+ *     the chosen xform with ONE level of address arithmetic (no pointer chasing).
  *
+ *     program header (int32 x 8):
  *       prog[0]  FL_PROG_MAGIC
  *       prog[1]  nxf        number of selectable xforms (string-sorted key order,
  *                            cuburn/genome/use.py:88-91)
@@ -74,26 +77,26 @@ typedef struct fl_mwc {
  *       prog[3]  pstride    floats per temporal-sample parameter block
  *       prog[4]  cdf_off    block offset of CDF[nxf] (cuburn/code/iter.py:12-30; entry
  *                            nxf-1 is stored too and is >= 1)
- *       prog[5..7] reserved (0)
- *       prog[8+i] i in [0, nxf+has_final): word offset in prog of xform descriptor i
- *                            (the final xform, if any, is descriptor nxf)
- *     xform descriptor:
- *       d[0] poff    block offset of the xform float record
- *       d[1] xflags  bit0: has post affine
- *       d[2] nvar    number of variations (sorted-name order, cuburn/code/iter.py:132)
- *       d[3+2j] variation id (flam3 numbering, cuburn/genome/variations.py:28-127)
- *       d[4+2j] voff: block offset of variation record {weight, params...}
- *     xform float record at poff:
- *       pre affine xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:81-95) ; if bit0: post affine
- *       (same six) ; color ; color_speed
- *     parameter block, floats [0..5]: camera xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:56-79)
- *     variation record: weight, then the variation's genome parameters in sorted-name
- *       order, then its precalculated values (see fl_var_info).
+ *       prog[5]  xf_off     block offset of xform record 0
+ *       prog[6]  xf_stride  floats per xform record (multiple of 4)
+ *       prog[7]  var_stride floats per variation record (>= 2)
+ *     parameter block (32-bit words; floats unless noted):
+ *       [0..5]   camera xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:56-79)
+ *       xform record i (i = nxf is the final xform) at xf_off + i * xf_stride:
+ *         [0..5]  pre affine xx,xy,xo,yx,yy,yo (cuburn/code/iter.py:81-95)
+ *         [6..11] post affine (same six; unused unless the flag below says so)
+ *         [12] color   [13] color_speed
+ *         [14] INT: nvar | (has_post << 8)      [15] reserved
+ *         variation j (sorted-name order, cuburn/code/iter.py:132) at 16 + j * var_stride:
+ *           [0] INT flam3 variation number (cuburn/genome/variations.py:28-127)
+ *           [1] weight   [2..] the variation's genome parameters in sorted-name order,
+ *                              then its precalculated values (cuburn_amd/genome/variations.py)
  */
-#define FL_PROG_MAGIC 0x464c5031 /* 'FLP1' */
+#define FL_PROG_MAGIC 0x464c5032 /* 'FLP2' */
 #define FL_PROG_HDR 8
 #define FL_MAX_XFORMS 64
-#define FL_MAX_PSTRIDE 1024 /* cuburn/render.py:185 max_params */
+#define FL_MAX_PSTRIDE 4096
+#define FL_XF_HDR 16      /* words of an xform record before its first variation */
 
 /* (6) Interpolation op list (int32 x 4 per op) — replaces the generated
  *     interp_iter_params kernel body (cuburn/code/interp.py:234-272) and the precalc
@@ -114,7 +117,8 @@ enum {
     FL_OP_INVSQ = 6,      /* dst <- 1/(v*v + 1e-20), v = row a  (waves, variations.py:136-140) */
     FL_OP_PERSP = 7,      /* dst[0..2] <- mdist, sin, cos; row a = angle, row b = dist(mag)
                              (variations.py:267-273)                                     */
-    FL_OP_INVSQ_MAX = 8   /* dst <- 1/max(1e-20, v*v), v = row a (mag)  (curve, variations.py:630-634) */
+    FL_OP_INVSQ_MAX = 8,  /* dst <- 1/max(1e-20, v*v), v = row a (mag)  (curve, variations.py:630-634) */
+    FL_OP_CONST = 9       /* dst <- the 32 bits of a (structure words: variation numbers, counts) */
 };
 
 /* ------------------------------------------------------------------------------------
@@ -230,6 +234,9 @@ int fl_debug_clear(fl_ctx *ctx, uint32_t w, uint32_t h, int reset_points);
 int fl_debug_clear_hot(fl_ctx *ctx, uint32_t w, uint32_t h);
 /* Point-shuffle tap: out[dst_thread] = src_thread after one swap with round counter `round`. */
 int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
+/* Xform tap: apply xform `xfi` (nxf = the final xform) of temporal sample `ts` once to n points
+ * {x, y, color, unused} with one RNG state each; results overwrite the inputs. */
+int fl_debug_apply_xf(fl_ctx *ctx, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
 int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
 

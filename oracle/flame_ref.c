@@ -602,28 +602,33 @@ int ref_var_supported(int id)
 }
 
 /* cuburn/code/iter.py:121-149: pre affine -> sum of variations -> optional post affine ->
- * colour blend.  Affine / blend spelled with explicit fmaf (device model agreement). */
+ * colour blend.  Affine / blend spelled with explicit fmaf (device model agreement).
+ * Record layout: include/flame_hip.h (5). */
 int ref_apply_xf(const int32_t *prog, const float *P, int xfi, float *px, float *py, float *pc, ref_mwc *r)
 {
-    const int32_t *d = prog + prog[8 + xfi];
-    const float *xf = P + d[0];
-    int post = d[1] & 1, nvar = d[2];
+    const float *xf = P + prog[5] + (size_t)xfi * prog[6];
+    const int vstride = prog[7];
+    int32_t word14;
+    memcpy(&word14, &xf[14], 4);
+    int nvar = word14 & 0xff, post = (word14 >> 8) & 1;
     float x = *px, y = *py;
     float tx = fmaf(xf[0], x, fmaf(xf[1], y, xf[2]));
     float ty = fmaf(xf[3], x, fmaf(xf[4], y, xf[5]));
     float ox = 0.0f, oy = 0.0f;
-    for (int j = 0; j < nvar; ++j)
-        if (var_apply(d[3 + 2 * j], P + d[4 + 2 * j], xf, &tx, &ty, &ox, &oy, r)) return -1;
-    const float *cp = xf + 6;
+    for (int j = 0; j < nvar; ++j) {
+        const float *v = xf + 16 + j * vstride;
+        int32_t vid;
+        memcpy(&vid, &v[0], 4);
+        if (var_apply(vid, v + 1, xf, &tx, &ty, &ox, &oy, r)) return -1;
+    }
     if (post) {
         const float *q = xf + 6;
         float qx = fmaf(q[0], ox, fmaf(q[1], oy, q[2]));
         float qy = fmaf(q[3], ox, fmaf(q[4], oy, q[5]));
         ox = qx; oy = qy;
-        cp = xf + 12;
     }
-    float csp = cp[1];
-    *pc = fmaf(*pc, 1.0f - csp, cp[0] * csp);
+    float csp = xf[13];
+    *pc = fmaf(*pc, 1.0f - csp, xf[12] * csp);
     *px = ox;
     *py = oy;
     return 0;
@@ -639,11 +644,12 @@ static inline int select_xf(const int32_t *prog, const float *P, float sel)
     return nxf - 1;
 }
 
-/* cuburn/code/util.py:194-200 trunca = cvt.rni.s32.f32 (round to nearest even, saturating,
- * NaN -> 0), result reinterpreted as unsigned */
+/* cuburn/code/util.py:194-200 trunca = cvt.rni.s32.f32 (round to nearest even, saturating),
+ * result reinterpreted as unsigned.  PTX maps NaN to 0, which would plot a NaN point at column
+ * / row 0 of the gutter; here NaN is mapped out of range (the sample is dropped). */
 static inline uint32_t trunca(float f)
 {
-    if (f != f) return 0;
+    if (f != f) return 0x80000000u;
     if (f >= 2147483648.0f) return 0x7fffffffu;
     if (f <= -2147483648.0f) return 0x80000000u;
     return (uint32_t)(int32_t)rintf(f);
@@ -764,7 +770,7 @@ int ref_iter_launch(const ref_geom *g, const ref_dim *dim, const int32_t *prog, 
     const int nt = g->nw * g->wl;
     int pstride = prog[3];
     for (uint32_t s = 0; s < nslots; ++s) {
-        uint32_t ts = s & 1023;
+        uint32_t ts = s % 1024;
         if (iter_block(g, dim, prog, params + (size_t)ts * pstride, palette + (ts >> 4) * 256,
                        rng + (size_t)s * nt, points + (size_t)s * nt * 4, hot, atom, out4,
                        round0, nrounds, fuse, counters))

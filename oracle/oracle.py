@@ -318,8 +318,20 @@ def param_block(gnm, names, t, dim):
     cache = {}
     keys = sorted(gnm['xforms'].keys())
     out = []
+    def bits(i):
+        return float(np.array([i], dtype=np.int32).view(np.float32)[0])
     for name in names:
         p = tuple(name.split('.')) if isinstance(name, str) else tuple(name)
+        if p[0] == 'pad':
+            out.append(0.0)
+            continue
+        if p[-1] in ('#nvar', '#id'):              # integer structure words, include/flame_hip.h (5)
+            base = gnm['xforms'][p[1]] if p[0] == 'xforms' else gnm['final_xform']
+            if p[-1] == '#nvar':
+                out.append(bits(len(base.get('variations', {})) | ((1 if 'post_affine' in base else 0) << 8)))
+            else:
+                out.append(bits(vs[p[-2]]['num']))
+            continue
         if p[0] == 'camera':                       # cuburn/code/iter.py:56-79
             if 'cam' not in cache:
                 rot = np.float32(G.val(('camera', 'rotation'), *sd['camera.rotation'])) * np.float32(math.pi) / np.float32(180.0)
@@ -373,4 +385,4 @@ def param_block(gnm, names, t, dim):
                     out.append(1.0 / max(1e-20, l * l))
                 else:
                     raise KeyError(name)
-    return np.array(out, dtype=np.float64)
+    return np.array(out, dtype=np.float64)      # structure words carry int32 bit patterns (exact in f64)

@@ -70,7 +70,7 @@ def test_renderer_host_side_objects():
     rdr = render.Renderer(gnm, gprof)
     assert [f.name for f in rdr.filts] == ['yuv', 'bilateral', 'logscale', 'colorclip']
     assert len(rdr.packer) == rdr.packer.pstride
-    assert rdr.packer.packed[0] == ('camera', 'xx')
+    assert rdr.packer.packed[0] == ('camera', 'xx') and len(rdr.packer.prog) == 8
     assert isinstance(rdr.out, output.Output)
     assert render.Dimensions(1, 2, 3, 4, 5).astride == 5
     # default profile filter order (specs.py:107,130)

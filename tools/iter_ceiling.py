@@ -12,7 +12,7 @@ for cfgname in sys.argv[1:] or ['cfg2']:
     gprof = profile.wrap(prof, gnm)
     rdr = render.Renderer(gnm, gprof); g = rdr._handle(mgr.fb); mgr._copy(rdr, gnm)
     _lib.check(lib.fl_interp(mgr.fb.ctx, g, 1920, 1080, 0.5, 0.0))
-    for mode in (0, 2, 0, 2):
+    for mode in [int(m) for m in os.environ.get('MODES', '0,2,1').split(',')]:
         mgr.timings_reset()
         run = C.c_uint64()
         _lib.check(lib.fl_iterate(mgr.fb.ctx, g, 1920, 1080, float(2 ** 28), 256, mode, C.byref(run)))
