@@ -132,6 +132,157 @@ k_bilateral(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ src, 
     dst[gi] = out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Restructured DE pass (same arithmetic as k_bilateral, cuburn/code/filters.py:166-264, with the
+// tap-invariant work hoisted out of the 31-tap loop):
+//   * the image travels between passes as N = (x/w, y/w, z/w, w): the colour-difference term
+//     needs the normalised colour of every tap, and the weighted sums only need n*w;
+//   * Pw = w^dpow is computed once per pixel by the pass that produces the pixel;
+//   * RA = 1/(avg + 1e-6) is written by the second density blur;
+//   * the three exponentials of a tap are one: spa * exp2(cs*cdiff + ds*|dpw| - exp2(gs*grad));
+//   * the shear pattern is a template parameter, so tap offsets are immediates.
+// 2 transcendentals per tap instead of 8; ~35 VALU per tap instead of ~150.
+// cuburn/code/filters.py:8-17,26-34: round-to-nearest-even of slope * radius (compile time)
+template <int PATTERN> __device__ __forceinline__ constexpr int tap_dx(int r) {
+    constexpr int num[8] = {2, 0, 2, -2, 2, -1, 2, 1};         // slope_x * 2
+    const int v = num[PATTERN] * r;                            // = 2 * slope * r
+    return (v % 2 == 0) ? v / 2 : ((v - 1) / 2 % 2 == 0 ? (v - 1) / 2 : (v + 1) / 2);
+}
+template <int PATTERN> __device__ __forceinline__ constexpr int tap_dy(int r) {
+    constexpr int num[8] = {0, 2, 2, 2, 1, 2, -1, 2};          // slope_y * 2
+    const int v = num[PATTERN] * r;
+    return (v % 2 == 0) ? v / 2 : ((v - 1) / 2 % 2 == 0 ? (v - 1) / 2 : (v + 1) / 2);
+}
+
+__global__ void __launch_bounds__(256)
+k_de_prep(fl_dim d, float4 *__restrict__ N, float *__restrict__ Pw, const float4 *__restrict__ src, float dpow)
+{
+    PIX_IDX(d);
+    const float4 p = src[gi];
+    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
+    N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
+    Pw[gi] = fpow(p.w, dpow);
+}
+
+__global__ void __launch_bounds__(256)
+k_de_finish(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ N)
+{
+    PIX_IDX(d);
+    const float4 n = N[gi];
+    dst[gi] = make_float4(n.x * n.w, n.y * n.w, n.z * n.w, n.w);
+}
+
+// Tap addressing.  Interior blocks: the tap offset dy*astride+dx is wave-uniform, so it is folded
+// into the (scalar) base pointer and every load uses the same 32-bit lane offset.  Edge blocks
+// clamp per lane (cuburn/code/filters.py:22-35 reads through a clamping texture).
+// Measured alternatives on MI355X (1080p, per direction): this fully unrolled form 82-96 us
+// (~230 VGPR, 2 waves/SIMD, ~90 loads in flight per wave); rolled 4-tap chunks at 8 waves/SIMD
+// 118-129 us; raw buffer loads with scalar offsets 142-160 us.  The floor of this gather
+// structure is the L1/TA rate (776 B per pixel through a 64 B/clk/CU port ~ 49 us).
+template <int PATTERN, bool EDGE, typename T>
+__device__ __forceinline__ T tap_load(const fl_dim &d, const T *__restrict__ buf, int xi, int yi, uint32_t gi, int r)
+{
+    const int dx = tap_dx<PATTERN>(r), dy = tap_dy<PATTERN>(r);
+    if (!EDGE) {
+        const T *__restrict__ shifted = buf + (dy * (int)d.astride + dx);     // uniform
+        return shifted[gi];
+    }
+    const int xs = min(max(xi + dx, 0), (int)d.astride - 1), ys = min(max(yi + dy, 0), (int)d.ah - 1);
+    return buf[(uint32_t)(ys * (int)d.astride + xs)];
+}
+
+template <int PATTERN, bool EDGE>
+__device__ __forceinline__ void de_taps(const fl_dim &d, int xi, int yi, uint32_t gi,
+                                        const float4 *__restrict__ N, const float *__restrict__ Pw,
+                                        const float *__restrict__ RA, const float *spa,
+                                        float cs2, float ds, float gs, float4 &out, float &weightsum)
+{
+    const float4 cen = N[gi];
+    // the reference normalises the centre with 1/(w + 1e-6) and the taps with 1/w
+    const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
+    const float cx = cen.x * cfix, cy = cen.y * cfix, cz = cen.z * cfix;
+    const float cpow = Pw[gi];
+    const bool cen_live = cen.w > 0.0f;
+    float wprev = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, -16).w;
+    float4 pix = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, -15);
+#pragma unroll
+    for (int r0 = -15; r0 <= 15; r0 += 8) {
+        float4 nx[8];
+        float pw[8], ra[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k;
+            if (r <= 15) {
+                nx[k] = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, r + 1);
+                pw[k] = tap_load<PATTERN, EDGE>(d, Pw, xi, yi, gi, r);
+                ra[k] = tap_load<PATTERN, EDGE>(d, RA, xi, yi, gi, r);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k;
+            if (r <= 15) {
+                const float yd = pix.x - cx, ud = pix.y - cy, vd = pix.z - cz;
+                float cdiff = yd * yd + ud * ud + vd * vd;
+                cdiff = (pix.w > 0.0f && cen_live) ? cdiff : 0.5f;
+                float e = cs2 * cdiff + ds * fabsf(cpow - pw[k]);
+                if (r != 0) {
+                    const float g = (nx[k].w - wprev) * ra[k];
+                    e -= fexp2(r < 0 ? -gs * g : gs * g);
+                }
+                const float factor = spa[r < 0 ? -r : r] * fexp2(e);
+                weightsum += factor;
+                const float fw = factor * pix.w;
+                out.x += fw * pix.x; out.y += fw * pix.y; out.z += fw * pix.z; out.w += fw;
+                wprev = pix.w;
+                pix = nx[k];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int PATTERN>
+__global__ void __launch_bounds__(256)
+k_de_bilateral(fl_dim d, float4 *__restrict__ Nout, float *__restrict__ Pout,
+               const float4 *__restrict__ N, const float *__restrict__ Pw, const float *__restrict__ RA,
+               float sstd, float cstd, float dstd, float dpow, float gspeed)
+{
+    PIX_IDX(d);
+    __shared__ float spa[16];
+    const int lt = threadIdx.y * blockDim.x + threadIdx.x;
+    if (lt < 16) { const float df = (float)lt; spa[lt] = fexp(fdiv(df * df, -FM_SQRT2 * sstd)); }
+    const float cs2 = frcp(-FM_SQRT2 * 3.0f * cstd) * FM_LOG2E;       // exp(c*x) = exp2(c*log2e*x)
+    const float ds = fdiv(-0.5f, dstd);
+    __syncthreads();
+    float4 out = make_float4(0, 0, 0, 0);
+    float weightsum = 0.0f;
+    // block-uniform: blocks whose taps stay inside the buffer skip the clamps
+    const int bx0 = blockIdx.x * blockDim.x, by0 = blockIdx.y * blockDim.y;
+    const bool interior = bx0 >= 17 && bx0 + (int)blockDim.x + 17 <= (int)d.astride &&
+                          by0 >= 17 && by0 + (int)blockDim.y + 17 <= (int)d.ah;
+    if (interior) de_taps<PATTERN, false>(d, xi, yi, (uint32_t)gi, N, Pw, RA, spa, cs2, ds, gspeed, out, weightsum);
+    else de_taps<PATTERN, true>(d, xi, yi, (uint32_t)gi, N, Pw, RA, spa, cs2, ds, gspeed, out, weightsum);
+    // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the 1/weightsum
+    // of the reference cancels), the density is out.w / (weightsum + 1e-10)
+    const float wn = out.w * frcp(weightsum + 1e-10f);
+    const float rn = out.w > 0.0f ? frcp(out.w) : 0.0f;
+    Nout[gi] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
+    Pout[gi] = fpow(wn, dpow);
+}
+
+// second density blur writing 1/(avg + 1e-6) (cuburn/code/filters.py:120-131 + :247)
+__global__ void __launch_bounds__(256)
+k_den_blur_1c_rcp(fl_dim d, float *__restrict__ dst, const float *__restrict__ src, int pattern, int upsample, Coefs7 k) {
+    PIX_IDX(d);
+    const float2 pat = shear_patterns[pattern];
+    float den = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        den += src[shear_idx(d, pat, xi, yi, (float)((i - 3) * (1 << upsample)))] * k.c[i];
+    dst[gi] = frcp(den + 1.0e-6f);
+}
+
 // cuburn/code/filters.py:41-53
 __global__ void __launch_bounds__(256) k_logscale(fl_dim d, float4 *__restrict__ buf, float k1, float k2) {
     PIX_IDX(d);
@@ -260,6 +411,15 @@ void launch_full_blur(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 void launch_bilateral(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, const float *blur, int pattern, int radius,
                       float sstd, float cstd, float dstd, float dpow, float gspeed) {
     hipLaunchKernelGGL(k_bilateral, GRID(d), 0, st, d, dst, src, blur, pattern, radius, sstd, cstd, dstd, dpow, gspeed);
+}
+void launch_de_prep(hipStream_t st, fl_dim d, float4 *N, float *Pw, const float4 *src, float dpow) { hipLaunchKernelGGL(k_de_prep, GRID(d), 0, st, d, N, Pw, src, dpow); }
+void launch_de_finish(hipStream_t st, fl_dim d, float4 *dst, const float4 *N) { hipLaunchKernelGGL(k_de_finish, GRID(d), 0, st, d, dst, N); }
+void launch_den_blur_1c_rcp(hipStream_t st, fl_dim d, float *dst, const float *src, int p, int up, const float *c) { hipLaunchKernelGGL(k_den_blur_1c_rcp, GRID(d), 0, st, d, dst, src, p, up, mk(c)); }
+void launch_de_bilateral(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *Pout, const float4 *N, const float *Pw,
+                         const float *RA, float sstd, float cstd, float dstd, float dpow, float gspeed) {
+#define DE(P) case P: hipLaunchKernelGGL(k_de_bilateral<P>, GRID(d), 0, st, d, Nout, Pout, N, Pw, RA, sstd, cstd, dstd, dpow, gspeed); break
+    switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
+#undef DE
 }
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2) { hipLaunchKernelGGL(k_logscale, GRID(d), 0, st, d, buf, k1, k2); }
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float hp, float gam, float lin, float lingam) { hipLaunchKernelGGL(k_colorclip, GRID(d), 0, st, d, buf, vib, hp, gam, lin, lingam); }

@@ -451,12 +451,28 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
-        for (int pat = 0; pat < 8; ++pat) {
-            launch_den_blur(st, d, c->d_blur, c->d_front, pat, 0, k7);
-            launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, pat, 1, k7);
-            launch_bilateral(st, d, c->d_back, c->d_front, (const float *)c->d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
-            std::swap(c->d_front, c->d_back);
+        if (getenv("FLAME_DE_REFERENCE_FORM")) {         // the literal per-tap form of the reference kernel
+            for (int pat = 0; pat < 8; ++pat) {
+                launch_den_blur(st, d, c->d_blur, c->d_front, pat, 0, k7);
+                launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, pat, 1, k7);
+                launch_bilateral(st, d, c->d_back, c->d_front, (const float *)c->d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
+                std::swap(c->d_front, c->d_back);
+            }
+            break;
         }
+        // planes carved from the float4 side buffer: RA = 1/(avg+1e-6), Pa / Pb = w^dpow ping-pong
+        const size_t nb = (size_t)d.ah * d.astride;
+        float *RA = (float *)c->d_side, *Pa = RA + nb, *Pb = Pa + nb;
+        float4 *Na = c->d_back, *Nb = c->d_front;
+        launch_de_prep(st, d, Na, Pa, c->d_front, p[3]);          // front(x,y,z,w) -> Na, Pa
+        for (int pat = 0; pat < 8; ++pat) {
+            launch_den_blur(st, d, c->d_blur, Na, pat, 0, k7);
+            launch_den_blur_1c_rcp(st, d, RA, c->d_blur, pat, 1, k7);
+            launch_de_bilateral(st, d, pat, Nb, Pb, Na, Pa, RA, p[0], p[1], p[2], p[3], p[4]);
+            std::swap(Na, Nb); std::swap(Pa, Pb);
+        }
+        // 8 swaps: the result sits in Na == d_back; un-normalise it into d_front
+        launch_de_finish(st, d, c->d_front, Na);
     } break;
     case FL_FILT_LOGSCALE:
         REQUIRE(np >= 2, "logscale needs k1,k2");
