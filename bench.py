@@ -14,8 +14,12 @@ in the data path) and the finished 8-bit frames are gathered to rank 0 over RCCL
 
 Prints ONE JSON line on rank 0:
   value     = write-enabled chaos-game samples per second, whole job (Msamples/s)
-  roofline  = dominant kernel (k_iter): algorithmic 16 B/sample (8-byte read-modify-write of the
-              packed cell) x samples / HIP-event kernel time, vs the 8 TB/s HBM peak
+  roofline  = dominant kernel (k_iter): algorithmic 16 B/sample (the 8-byte
+              read-modify-write of the packed cell) x samples per launch / HIP-event launch time,
+              vs the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from the TCC counters
+              (profiles/r01_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+              passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  `pipeline` is the same
+              figure over the whole iterate+accumulate chain (k_iter + k_accum_tiles + k_flush).
   cpu_baseline = the oracle's flam3-style chaos game on the host cores (rank 0, N=1 only)
 """
 import argparse
@@ -136,6 +140,17 @@ def main():
         samples_total = acc['samples'] * world            # every rank runs the same workload
         iter_s = acc['iter_ms'] * 1e-3
         achieved = 16.0 * acc['samples'] / iter_s / 1e9 if iter_s > 0 else 0.0
+        pipe_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
+        pipe = 16.0 * acc['samples'] / pipe_s / 1e9 if pipe_s > 0 else 0.0
+        traffic = None
+        try:        # measured offline with tools/pmc_traffic.sh on this workload (KB units, reads x2)
+            pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')))
+            key = [k for k in pmc if 'k_iter' in k and ((', 1>' in k) == (args.accum == 'binned'))]
+            if key and args.config == 'cfg2':
+                c = pmc[key[0]]
+                traffic = int((2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024)
+        except Exception:
+            traffic = None
         de_bytes = 512.0 * nbins * args.steps              # 64 B/px/direction x 8
         out = {
             'metric': 'Msamples/s into 1920x1080 histogram + DE-filter GB/s vs HBM roofline',
@@ -151,14 +166,15 @@ def main():
                        'accum': args.accum, 'frames_per_gpu': args.steps,
                        'parallelism': 'frame-sharded x%d, RCCL gather' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'pipeline': {'kernels': 'k_iter+k_accum_tiles+k_flush', 'achieved': round(pipe, 2), 'frac': round(pipe / HBM_PEAK_GBS, 5)},
                          'avg_launch_ms': round(acc['iter_ms'] / max(acc['launches'], 1), 4),
                          'iter_msamples_per_s': round(acc['samples'] / iter_s / 1e6, 1) if iter_s > 0 else 0.0},
             'de_filter': {'gbps': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9, 2) if acc['filter_ms'] > 0 else 0.0,
                           'frac_of_peak': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if acc['filter_ms'] > 0 else 0.0,
                           'note': 'algorithmic 512 B/px over the whole filter chain time (yuv+bilateral+logscale+colorclip)',
                           'filter_ms_per_frame': round(acc['filter_ms'] / args.steps, 4)},
-            'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / args.steps, 4), 'flush': round(acc['flush_ms'] / args.steps, 4),
+            'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / args.steps, 4), 'accum_flush': round(acc['flush_ms'] / args.steps, 4),
                                     'filters': round(acc['filter_ms'] / args.steps, 4)},
         }
         if world == 1 and args.cpu_seconds > 0:

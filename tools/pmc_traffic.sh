@@ -1,0 +1,23 @@
+#!/bin/bash
+# HBM traffic of the bench kernels from the TCC counters, two separate passes (FETCH_SIZE needs 3
+# TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Usage: tools/pmc_traffic.sh <tag>
+export TMPDIR=/tmp
+tag=$1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_${tag}_$ctr -o b -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 > gpurun_out/pmc_${tag}_$ctr.log 2>&1
+done
+python3 - <<PY
+import csv, collections, json
+out = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = list(csv.DictReader(open("gpurun_out/pmc_${tag}_%s/b_counter_collection.csv" % ctr)))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        per[r["Kernel_Name"].split("(")[0]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for k, d in per.items():
+        vals = sorted(d.values())
+        out.setdefault(k, {})[ctr] = {"n": len(vals), "median_per_launch": vals[len(vals) // 2], "max": vals[-1]}
+json.dump(out, open("gpurun_out/pmc_${tag}_traffic.json", "w"), indent=1, sort_keys=True)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("WRITE_SIZE", {}).get("median_per_launch", 0)):
+    print(k[:60].ljust(60), {c: round(x["median_per_launch"], 1) for c, x in v.items()})
+PY
