@@ -91,6 +91,8 @@ def main():
     gprof = profile.wrap(prof, gnm)
     mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1024)), host_seed=42 + rank)
     mgr.accum_mode = _lib.ACCUM_BINNED if args.accum == 'binned' else _lib.ACCUM_ATOMIC
+    if 'FLAME_FUSE' in os.environ:
+        mgr.fuse = int(os.environ['FLAME_FUSE'])
     rdr = render.Renderer(gnm, gprof)
     w, h = gprof.width, gprof.height
     frame = torch.empty((h, w, 4), dtype=torch.uint8, device='cuda')
@@ -163,7 +165,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
                        'samples_per_frame': acc['samples'] // max(args.steps, 1),
-                       'accum': args.accum, 'frames_per_gpu': args.steps,
+                       'accum': args.accum, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
                        'parallelism': 'frame-sharded x%d, RCCL gather' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,

@@ -20,27 +20,43 @@ __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_
     return ((w + sh) % NW) * 64u + l;
 }
 
+// The first 18 words of an xform record (include/flame_hip.h (5)): affines, colour, structure
+// word, and the number + weight of the first variation.  Held in SGPRs.
+struct XfHead { float f[16]; int vid0; float w0; };
+
+__device__ __forceinline__ XfHead load_head(const float *__restrict__ xf) {
+    XfHead h;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h.f[i] = xf[i];
+    h.vid0 = __float_as_int(xf[FL_XF_HDR]);
+    h.w0 = xf[FL_XF_HDR + 1];
+    return h;
+}
+
 // cuburn/code/iter.py:121-149: pre affine, sum of variations, optional post affine, colour
-// blend.  `xfi` is wave-uniform; the record address is plain arithmetic on it (fixed strides,
-// include/flame_hip.h (5)), so every read below is an s_load with no pointer chasing.
-__device__ __forceinline__ void apply_xf(const float *__restrict__ P, int xf_off, int xf_stride, int var_stride,
-                                         int xfi, float &x, float &y, float &c, mwc_t &r)
+// blend.  The record is wave-uniform; `h` was loaded a round ahead (its choice depends only on
+// the RNG), so the s_load latency of the record is off the critical path; only parameters of
+// parametric variations and variations beyond the first are loaded on demand.
+__device__ __forceinline__ void apply_xf(const XfHead &h, const float *__restrict__ xf, int var_stride,
+                                         float &x, float &y, float &c, mwc_t &r)
 {
-    const float *__restrict__ xf = P + xf_off + xfi * xf_stride;
-    const int word14 = __float_as_int(xf[14]);
+    const int word14 = __float_as_int(h.f[14]);
     const int nvar = word14 & 0xff;
-    float tx = fmaf(xf[0], x, fmaf(xf[1], y, xf[2]));
-    float ty = fmaf(xf[3], x, fmaf(xf[4], y, xf[5]));
+    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, h.f[2]));
+    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, h.f[5]));
     float ox = 0.0f, oy = 0.0f;
-    for (int j = 0; j < nvar; ++j)
-        apply_variation(xf + FL_XF_HDR + j * var_stride, xf, tx, ty, ox, oy, r);
+    if (nvar > 0) apply_variation(h.vid0, h.w0, xf + FL_XF_HDR + 2, xf, tx, ty, ox, oy, r);
+    for (int j = 1; j < nvar; ++j) {
+        const float *__restrict__ v = xf + FL_XF_HDR + j * var_stride;
+        apply_variation(__float_as_int(v[0]), v[1], v + 2, xf, tx, ty, ox, oy, r);
+    }
     if (word14 & 0x100) {
-        const float qx = fmaf(xf[6], ox, fmaf(xf[7], oy, xf[8]));
-        const float qy = fmaf(xf[9], ox, fmaf(xf[10], oy, xf[11]));
+        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, h.f[8]));
+        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, h.f[11]));
         ox = qx; oy = qy;
     }
-    const float csp = xf[13];
-    c = fmaf(c, 1.0f - csp, xf[12] * csp);
+    const float csp = h.f[13];
+    c = fmaf(c, 1.0f - csp, h.f[12] * csp);
     x = ox; y = oy;
 }
 
@@ -129,6 +145,9 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     const float color_dither = 0.49f * mwc_next_11(rctx);                   // iter.py:185
     if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);          // iter.py:209-216
     __syncthreads();
+    // camera and final xform are constant for the slot
+    const float cam0 = P[0], cam1 = P[1], cam2 = P[2], cam3 = P[3], cam4 = P[4], cam5 = P[5];
+    const float *__restrict__ xf_final = P + xf_off + nxf * xf_stride;
 
     uint32_t phase = round0 % 3u;
     // cumulative xform densities of this slot's temporal sample: constant for the whole launch
@@ -140,11 +159,10 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
     bool pend_ok = false; uint32_t pend_gi = 0; float pend_mult = 1.0f; u64 pend_old = 0;
 
-    for (uint32_t rd = 0; rd < nrounds; ++rd) {
-        if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
-
-        // wave-coherent xform choice: lane 0's draw (iter.py:260-272 uses a shared cosel[])
-        const uint32_t sel = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
+    // Wave-coherent xform choice: lane 0's draw (iter.py:260-272 uses a shared cosel[]).  The
+    // selector of round r+1 is drawn at the top of round r, so the record it picks can be
+    // fetched a whole round before it is needed.
+    auto choose = [&](uint32_t sel) -> int {
         const float xfsel = (float)sel * (1.0f / 4294967296.0f);
         int k;
         if (nxf <= 8) {
@@ -156,8 +174,22 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
             k = nxf - 1;
             for (int i = nxf - 2; i >= 0; --i) if (xfsel <= P[cdf_off + i]) k = i;
         }
-        k = __builtin_amdgcn_readfirstlane(k);
-        apply_xf(P, xf_off, xf_stride, var_stride, k, x, y, color, rctx);
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+    uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
+    const float *__restrict__ xf_next = P + xf_off + choose(sel_next) * xf_stride;
+    XfHead hnext = load_head(xf_next);
+
+    for (uint32_t rd = 0; rd < nrounds; ++rd) {
+        if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
+
+        const uint32_t sel = sel_next;
+        const float *__restrict__ xf_cur = xf_next;
+        const XfHead hcur = hnext;
+        sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
+        xf_next = P + xf_off + choose(sel_next) * xf_stride;
+        hnext = load_head(xf_next);                                         // arrives during this round
+        apply_xf(hcur, xf_cur, var_stride, x, y, color, rctx);
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
@@ -170,9 +202,9 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         if (rd < fuse) continue;                                            // iter.py:298-300
 
         float fx = x, fy = y, fc = color;
-        if (has_final) apply_xf(P, xf_off, xf_stride, var_stride, nxf, fx, fy, fc, rctx);   // iter.py:302-307
-        const float cx = fmaf(P[0], fx, fmaf(P[1], fy, P[2]));              // iter.py:306-309
-        const float cy = fmaf(P[3], fx, fmaf(P[4], fy, P[5]));
+        if (has_final) { const XfHead hfin = load_head(xf_final); apply_xf(hfin, xf_final, var_stride, fx, fy, fc, rctx); }   // iter.py:302-307
+        const float cx = fmaf(cam0, fx, fmaf(cam1, fy, cam2));              // iter.py:306-309
+        const float cy = fmaf(cam3, fx, fmaf(cam4, fy, cam5));
         // iter.py:313-317: round to nearest even, reject outside [0, astride) x [0, aheight).
         // Done in the float domain (both limits are even, so x.5 ties round outward at the top
         // and to 0 at the bottom): one compare chain instead of two saturating conversions.
@@ -272,7 +304,9 @@ k_apply_xf_tap(const int32_t *__restrict__ prog, const float *__restrict__ param
     const float *__restrict__ P = params + (size_t)ts * prog[3];
     mwc_t r = {rng[i].mul, rng[i].state, rng[i].carry};
     float4 p = pts[i];
-    apply_xf(P, prog[5], prog[6], prog[7], xfi, p.x, p.y, p.z, r);
+    const float *__restrict__ xf = P + prog[5] + xfi * prog[6];
+    const XfHead h = load_head(xf);
+    apply_xf(h, xf, prog[7], p.x, p.y, p.z, r);
     pts[i] = p;
     rng[i].mul = r.mul; rng[i].state = r.state; rng[i].carry = r.carry;
 }

@@ -319,12 +319,11 @@ __device__ __noinline__ VarIO apply_variation_slow(int id, float w, const float 
     return io;
 }
 
-// v points at the variation record {id, weight, params...} (include/flame_hip.h (5)).
-__device__ __forceinline__ void apply_variation(const float *__restrict__ v, const float *__restrict__ xf,
+// id / w: the variation's number and weight; v points at its parameters (include/flame_hip.h (5)).
+__device__ __forceinline__ void apply_variation(int id, float w, const float *__restrict__ v,
+                                                const float *__restrict__ xf,
                                                 float &tx, float &ty, float &ox, float &oy, mwc_t &r)
 {
-    const int id = __float_as_int(v[0]);
-    const float w = v[1];
     const float r2 = fmaf(tx, tx, ty * ty);
     if (id == 0) { OUT(tx * VW, ty * VW); }                                             // linear
     else if (id == 2) { float k = fdiv(VW, r2); OUT(tx * k, ty * k); }                  // spherical
@@ -339,7 +338,7 @@ __device__ __forceinline__ void apply_variation(const float *__restrict__ v, con
                          OUT(VW * nx * tx, VW * ny * ty); }
     else {
         VarIO io = {tx, ty, ox, oy, r.state, r.carry};
-        io = apply_variation_slow(id, w, v + 2, xf, io, r.mul);
+        io = apply_variation_slow(id, w, v, xf, io, r.mul);
         tx = io.tx; ty = io.ty; ox = io.ox; oy = io.oy; r.state = io.state; r.carry = io.carry;
     }
 }

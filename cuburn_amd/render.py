@@ -164,7 +164,12 @@ class RenderManager(object):
     # 'auto': binned accumulate (sample log + LDS tiles) whenever the image has <= 2047 tiles of
     # 128x64 pixels (up to 4K), else direct packed global atomics.  Both give the same histogram.
     accum_mode = 'auto'
-    fuse = 256                      # write-disabled iterations per walker per frame (render.py:215)
+    # Write-disabled iterations per walker at the start of a frame.  The reference's value is 256
+    # (render.py:215: one whole round block, a by-product of its launch granularity); flam3 uses 15.
+    # The CPU device model shows the start-up transient is gone after 16 iterations for the
+    # BASELINE flames even when only 8 write rounds follow (DESIGN.md §4.1 'fuse'); 64 keeps a 4x
+    # margin.  Set to 256 for the reference's literal schedule.
+    fuse = 64
 
     def __init__(self, device=None, nslots=1024, host_seed=None, stream=None):
         if device is None:

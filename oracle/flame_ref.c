@@ -693,6 +693,7 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
     float *sx = malloc(sizeof(float) * nt * 3), *sy = sx + nt, *sc = sy + nt;
     float *dith = malloc(sizeof(float) * nt);
     uint32_t *sel = malloc(sizeof(uint32_t) * nt);
+    uint32_t *sel_next = malloc(sizeof(uint32_t) * nt);
     for (int t = 0; t < nt; ++t) {
         dith[t] = 0.49f * ref_mwc_next_11(&rng[t]);                 /* iter.py:185 */
         float x = pts[4 * t], y = pts[4 * t + 1];
@@ -701,6 +702,7 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
             pts[4 * t + 1] = ref_mwc_next_11(&rng[t]);
             pts[4 * t + 2] = ref_mwc_next_01(&rng[t]);
         }
+        sel_next[t] = ref_mwc_next(&rng[t]);                        /* selector of round 0 */
     }
     for (uint32_t rd = 0; rd < nrounds; ++rd) {
         uint32_t R = round0 + rd;
@@ -711,7 +713,10 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
                 pts[4 * t + 1] = ref_mwc_next_11(&rng[t]);
                 pts[4 * t + 2] = ref_mwc_next_01(&rng[t]);
             }
-            sel[t] = ref_mwc_next(&rng[t]);
+            /* device model: the selector of round r+1 is drawn at the top of round r (so the
+             * kernel can fetch the chosen record a round ahead); the last one goes unused */
+            sel[t] = sel_next[t];
+            sel_next[t] = ref_mwc_next(&rng[t]);
         }
         for (int t = 0; t < nt; ++t) {
             int wv = t / g->wl, l = t % g->wl;
@@ -719,7 +724,7 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
             float xfsel = (float)s * (1.0f / 4294967296.0f);
             int k = select_xf(prog, P, xfsel);
             float x = pts[4 * t], y = pts[4 * t + 1], c = pts[4 * t + 2];
-            if (ref_apply_xf(prog, P, k, &x, &y, &c, &rng[t])) { free(sx); free(dith); free(sel); return -1; }
+            if (ref_apply_xf(prog, P, k, &x, &y, &c, &rng[t])) { free(sx); free(dith); free(sel); free(sel_next); return -1; }
             uint32_t dst = shuffle_dest(g, wv, l, R);                /* iter.py:274-283 */
             sx[dst] = x; sy[dst] = y; sc[dst] = c;
         }
@@ -730,7 +735,7 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
         for (int t = 0; t < nt; ++t) {
             float x = pts[4 * t], y = pts[4 * t + 1], cc = pts[4 * t + 2];
             if (has_final) {                                         /* iter.py:302-307 */
-                if (ref_apply_xf(prog, P, nxf, &x, &y, &cc, &rng[t])) { free(sx); free(dith); free(sel); return -1; }
+                if (ref_apply_xf(prog, P, nxf, &x, &y, &cc, &rng[t])) { free(sx); free(dith); free(sel); free(sel_next); return -1; }
             }
             float cx = fmaf(P[0], x, fmaf(P[1], y, P[2]));           /* iter.py:306-309 */
             float cy = fmaf(P[3], x, fmaf(P[4], y, P[5]));
@@ -756,7 +761,7 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
             }
         }
     }
-    free(sx); free(dith); free(sel);
+    free(sx); free(dith); free(sel); free(sel_next);
     return 0;
 }
 
