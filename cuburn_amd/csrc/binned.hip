@@ -35,7 +35,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan_b(uint32_t v, uint32_t lane) 
     return v;
 }
 
+#ifndef ACC_ILP
 #define ACC_ILP 4
+#endif
 
 __global__ void __launch_bounds__(1024)
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
@@ -73,12 +75,14 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 const uint32_t v = v0 + k * 64 + lane;
                 // rightmost run r with excl[r] <= v (binary search over the 64 lanes' values)
                 uint32_t r = 0;
+#ifndef ACC_NOSEARCH
 #pragma unroll
                 for (int step = 32; step >= 1; step >>= 1) {
                     const uint32_t probe = r + step;
                     const uint32_t pe = __shfl(excl, probe & 63);
                     if (probe < 64 && pe <= v) r = probe;
                 }
+#endif
                 const uint32_t r_excl = __shfl(excl, r), r_first = __shfl(first, r);
                 live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
@@ -87,12 +91,20 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
             }
             u64 val[ACC_ILP];
 #pragma unroll
+#ifndef ACC_NOPAL
             for (int k = 0; k < ACC_ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+#else
+            for (int k = 0; k < ACC_ILP; ++k) val[k] = (1ull << 54) | rec[k];
+#endif
 #pragma unroll
             for (int k = 0; k < ACC_ILP; ++k) {
                 if (!live[k]) continue;
                 const uint32_t off = rec[k] >> 8;                                // (ly << 7) | lx
+#ifndef ACC_NOATOM
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                const u64 old = val[k]; if (off == 0x7fffffff) tile[0] = old;
+#endif
                 if ((uint32_t)(old >> 32) >= (256u << 23)) {
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {

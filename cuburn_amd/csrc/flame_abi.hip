@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "kernels.h"
+#include "flame_device.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const char *what, const char *file, int line, hipError_t e = hipSuccess)
@@ -27,14 +28,12 @@ static int fail(int code, const char *what, const char *file, int line, hipError
 
 struct EvPair { hipEvent_t a, b; };
 
-struct fl_ctx {
-    int device = 0;
+// One "lane" = a stream with its own framebuffers, sample log and per-frame parameter buffers.
+// Consecutive frames alternate between two lanes so that the drain + filter + output kernels of
+// frame k (bandwidth / TA bound) overlap the iterate kernel of frame k+1 (issue / latency bound),
+// the role of stream_a / stream_b in the reference (cuburn/render.py:253-262,432-433).
+struct Lane {
     hipStream_t stream = nullptr;
-    bool own_stream = false;
-    uint32_t nslots = 0, nwalkers = 0;
-    int nw = 4;                       // waves per iterate workgroup
-    fl_mwc *d_rng = nullptr;          // [nwalkers]; last FL_PAL_H*256 serve the palette kernel
-    float4 *d_points = nullptr;       // [nslots*256]
     size_t nbins = 0;
     float4 *d_front = nullptr, *d_back = nullptr, *d_side = nullptr;
     float *d_blur = nullptr;          // 1-channel scratch [nbins]
@@ -42,20 +41,40 @@ struct fl_ctx {
     uint32_t *d_hot = nullptr;
     void *d_outpix = nullptr;         // w*h*8 bytes
     size_t outpix_bytes = 0;
-    u64 *d_counters = nullptr;
     uint32_t *d_log = nullptr, *d_dir = nullptr;      // binned accumulate: sample log + directory
     size_t log_words = 0, dir_words = 0;
-    uint32_t bin_rounds = 12, bin_parts = 16;
     float *d_params = nullptr;        // [FL_NTEMPORAL * FL_MAX_PSTRIDE]
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
+    // cross-lane ordering of the state both lanes share
+    hipEvent_t ev_interp_done = nullptr;   // genome staging buffers + palette RNG states
+    hipEvent_t ev_iter_done = nullptr;     // walkers + their RNG states
+    hipEvent_t ev_out_done = nullptr;      // output-dither RNG states
+    bool interp_rec = false, iter_rec = false, out_rec = false;
+};
+
+struct fl_ctx {
+    int device = 0;
+    bool own_stream = false;
+    int nlanes = 2, cur = 0;
+    Lane lanes[2];
+    uint32_t nslots = 0, nwalkers = 0;
+    int nw = 4;                       // waves per iterate workgroup
+    fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
+    float4 *d_points = nullptr;       // [nslots*NT]
+    u64 *d_counters = nullptr;
+    uint32_t bin_rounds = 12, bin_parts = 16;
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
+    uint32_t frame_lane[kFrames] = {};
     uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
     std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev;
     size_t pool_used = 0;
     bool timing = true;
 };
+#define L(c) ((c)->lanes[(c)->cur])
+#define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
+#define FL_NOUT 65536u                // RNG states reserved for the output dither kernel
 
 struct fl_genome {
     std::vector<int32_t> prog;
@@ -87,10 +106,10 @@ static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
     }
     EvPair p = c->pool[c->pool_used++];
     list.push_back(p);
-    hipEventRecord(p.a, c->stream);
+    hipEventRecord(p.a, L(c).stream);
     return &c->pool[c->pool_used - 1];
 }
-static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, c->stream); }
+static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, L(c).stream); }
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -108,10 +127,10 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *o)
 
 static void free_fb(fl_ctx *c)
 {
-    hipFree(c->d_front); hipFree(c->d_back); hipFree(c->d_side); hipFree(c->d_blur);
-    hipFree(c->d_atom); hipFree(c->d_hot); hipFree(c->d_outpix);
-    c->d_front = c->d_back = c->d_side = nullptr; c->d_blur = nullptr; c->d_atom = nullptr;
-    c->d_hot = nullptr; c->d_outpix = nullptr; c->nbins = 0; c->outpix_bytes = 0;
+    hipFree(L(c).d_front); hipFree(L(c).d_back); hipFree(L(c).d_side); hipFree(L(c).d_blur);
+    hipFree(L(c).d_atom); hipFree(L(c).d_hot); hipFree(L(c).d_outpix);
+    L(c).d_front = L(c).d_back = L(c).d_side = nullptr; L(c).d_blur = nullptr; L(c).d_atom = nullptr;
+    L(c).d_hot = nullptr; L(c).d_outpix = nullptr; L(c).nbins = 0; L(c).outpix_bytes = 0;
 }
 
 // cuburn/render.py:121-161 Framebuffers.alloc / set_dim: grow-only; on OOM free everything
@@ -119,19 +138,19 @@ static void free_fb(fl_ctx *c)
 static int ensure_fb(fl_ctx *c, const fl_dim &d)
 {
     size_t nbins = (size_t)d.ah * d.astride, ob = (size_t)d.w * d.h * 8;
-    if (c->nbins >= nbins && c->outpix_bytes >= ob) return FL_OK;
-    hipStreamSynchronize(c->stream);
+    if (L(c).nbins >= nbins && L(c).outpix_bytes >= ob) return FL_OK;
+    hipStreamSynchronize(L(c).stream);
     free_fb(c);
     hipError_t e;
-    if ((e = hipMalloc(&c->d_front, 16 * nbins)) || (e = hipMalloc(&c->d_back, 16 * nbins)) ||
-        (e = hipMalloc(&c->d_side, 16 * nbins)) || (e = hipMalloc(&c->d_blur, 4 * nbins)) ||
-        (e = hipMalloc(&c->d_atom, 8 * nbins)) || (e = hipMalloc(&c->d_hot, 4 * (nbins / 16))) ||
-        (e = hipMalloc(&c->d_outpix, ob))) {
+    if ((e = hipMalloc(&L(c).d_front, 16 * nbins)) || (e = hipMalloc(&L(c).d_back, 16 * nbins)) ||
+        (e = hipMalloc(&L(c).d_side, 16 * nbins)) || (e = hipMalloc(&L(c).d_blur, 4 * nbins)) ||
+        (e = hipMalloc(&L(c).d_atom, 8 * nbins)) || (e = hipMalloc(&L(c).d_hot, 4 * (nbins / 16))) ||
+        (e = hipMalloc(&L(c).d_outpix, ob))) {
         free_fb(c);
         (void)hipGetLastError();
         return fail(e == hipErrorOutOfMemory ? FL_E_NOMEM : FL_E_HIP, "framebuffer allocation", __FILE__, __LINE__, e);
     }
-    c->nbins = nbins; c->outpix_bytes = ob;
+    L(c).nbins = nbins; L(c).outpix_bytes = ob;
     return FL_OK;
 }
 
@@ -149,20 +168,30 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
         return fail(FL_E_NODEV, "device is not gfx950 (kernels are built for MI355X only)", __FILE__, __LINE__);
     fl_ctx *c = new fl_ctx;
     c->device = device;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    if (const char *e = getenv("FLAME_LANES")) c->nlanes = atoi(e) == 1 ? 1 : 2;
+    if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
+    else {
+        for (int i = 0; i < c->nlanes; ++i) HIPCHK(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
     c->nslots = nslots;
     const char *env_nw = getenv("FLAME_NW");
     if (env_nw && atoi(env_nw) == 8) c->nw = 8;
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
-    c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256;
-    if (nseeds != c->nwalkers) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*nw*64 + 64*256", __FILE__, __LINE__); }
+    c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256 + FL_NOUT;
+    if (nseeds != c->nwalkers) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*nw*64 + 64*256 + 65536", __FILE__, __LINE__); }
     HIPCHK(hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers));
     HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * c->nw * 64));
     HIPCHK(hipMalloc(&c->d_counters, 8 * 4));
-    HIPCHK(hipMalloc(&c->d_params, sizeof(float) * FL_NTEMPORAL * FL_MAX_PSTRIDE));
-    HIPCHK(hipMalloc(&c->d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W));
+    for (int i = 0; i < c->nlanes; ++i) {
+        Lane &ln = c->lanes[i];
+        HIPCHK(hipMalloc(&ln.d_params, sizeof(float) * FL_NTEMPORAL * FL_MAX_PSTRIDE));
+        HIPCHK(hipMalloc(&ln.d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W));
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_interp_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_iter_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ln.ev_out_done, hipEventDisableTiming));
+    }
     HIPCHK(hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice));
     HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * c->nw * 64 * 4));
     HIPCHK(hipMemset(c->d_counters, 0, 32));
@@ -174,21 +203,41 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     return FL_OK;
 }
 
+static void sync_all(fl_ctx *c) { for (int i = 0; i < c->nlanes; ++i) hipStreamSynchronize(c->lanes[i].stream); }
+
 void fl_ctx_destroy(fl_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    free_fb(c);
-    hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters); hipFree(c->d_params); hipFree(c->d_palette);
-    hipFree(c->d_log); hipFree(c->d_dir);
+    sync_all(c);
+    for (int i = 0; i < c->nlanes; ++i) {
+        c->cur = i;
+        free_fb(c);
+        Lane &ln = c->lanes[i];
+        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_log); hipFree(ln.d_dir);
+        if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
+        if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
+        if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
+        if (c->own_stream) hipStreamDestroy(ln.stream);
+    }
+    hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters);
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) { hipEventDestroy(c->ev_begin_[i]); hipEventDestroy(c->ev_end_[i]); }
-    if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
-int fl_ctx_sync(fl_ctx *c) { REQUIRE(c, "null ctx"); HIPCHK(hipStreamSynchronize(c->stream)); return FL_OK; }
+int fl_ctx_sync(fl_ctx *c) { REQUIRE(c, "null ctx"); sync_all(c); return FL_OK; }
+
+// Make the current lane's stream wait for what the OTHER lane last did to state both share.
+static int wait_other(fl_ctx *c, int what)
+{
+    if (c->nlanes < 2) return FL_OK;
+    Lane &o = OTHER(c);
+    if (what == 0 && o.interp_rec) HIPCHK(hipStreamWaitEvent(L(c).stream, o.ev_interp_done, 0));
+    if (what == 1 && o.iter_rec) HIPCHK(hipStreamWaitEvent(L(c).stream, o.ev_iter_done, 0));
+    if (what == 2 && o.out_rec) HIPCHK(hipStreamWaitEvent(L(c).stream, o.ev_out_done, 0));
+    return FL_OK;
+}
 
 // Validate the program header before any kernel trusts it (the reference traps on device,
 // cuburn/code/iter.py:254-257).  Variation numbers live in the parameter block as FL_OP_CONST
@@ -286,11 +335,12 @@ int fl_genome_upload(fl_ctx *c, fl_genome *g, const float *times, const float *k
     memcpy(h + nb, knots, nb);
     memcpy(h + 2 * nb, pal_rgba, pb);
     memcpy(h + 2 * nb + pb, pal_times, tb);
-    HIPCHK(hipMemcpyAsync(g->d_times, h, nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(g->d_knots, h + nb, nb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(g->d_pals, h + 2 * nb, pb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(g->d_ptimes, h + 2 * nb + pb, tb, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipEventRecord(g->ev_stage[slot], c->stream));
+    { int rc = wait_other(c, 0); if (rc) return rc; }     // the other lane's interp still reads these buffers
+    HIPCHK(hipMemcpyAsync(g->d_times, h, nb, hipMemcpyHostToDevice, L(c).stream));
+    HIPCHK(hipMemcpyAsync(g->d_knots, h + nb, nb, hipMemcpyHostToDevice, L(c).stream));
+    HIPCHK(hipMemcpyAsync(g->d_pals, h + 2 * nb, pb, hipMemcpyHostToDevice, L(c).stream));
+    HIPCHK(hipMemcpyAsync(g->d_ptimes, h + 2 * nb + pb, tb, hipMemcpyHostToDevice, L(c).stream));
+    HIPCHK(hipEventRecord(g->ev_stage[slot], L(c).stream));
     g->npal = npal;
     return FL_OK;
 }
@@ -301,8 +351,10 @@ int fl_frame_begin(fl_ctx *c, uint32_t *frame_id)
     HIPCHK(hipSetDevice(c->device));
     const uint32_t id = c->frame_seq++;
     const uint32_t k = id % fl_ctx::kFrames;
-    HIPCHK(hipEventRecord(c->ev_begin_[k], c->stream));
-    HIPCHK(hipEventRecord(c->ev_end_[k], c->stream));       // moved forward by fl_output
+    c->cur = c->nlanes == 2 ? (int)(id & 1u) : 0;          // consecutive frames alternate lanes
+    c->frame_lane[k] = (uint32_t)c->cur;
+    HIPCHK(hipEventRecord(c->ev_begin_[k], L(c).stream));
+    HIPCHK(hipEventRecord(c->ev_end_[k], L(c).stream));       // moved forward by fl_output
     *frame_id = id;
     return FL_OK;
 }
@@ -313,10 +365,13 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * c->nw * 64;
-    launch_interp_palette(c->stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, c->d_palette);
-    launch_interp_params(c->stream, c->d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
+    { int rc = wait_other(c, 0); if (rc) return rc; }     // palette RNG states are shared
+    launch_interp_palette(L(c).stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, L(c).d_palette);
+    launch_interp_params(L(c).stream, L(c).d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
                          ts, td / FL_NTEMPORAL, d);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L(c).ev_interp_done, L(c).stream));
+    L(c).interp_rec = true;
     return FL_OK;
 }
 
@@ -324,11 +379,11 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
 {
     size_t nbins = (size_t)d.ah * d.astride;
     // cuburn/render.py:321-328
-    HIPCHK(hipMemsetAsync(c->d_front, 0, 16 * nbins, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_atom, 0, 8 * nbins, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_hot, 0, 4 * (nbins / 16), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
-    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * c->nw * 64 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(L(c).d_front, 0, 16 * nbins, L(c).stream));
+    HIPCHK(hipMemsetAsync(L(c).d_atom, 0, 8 * nbins, L(c).stream));
+    HIPCHK(hipMemsetAsync(L(c).d_hot, 0, 4 * (nbins / 16), L(c).stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, L(c).stream));
+    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * c->nw * 64 * 4, L(c).stream));
     return FL_OK;
 }
 
@@ -340,22 +395,22 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint
 {
     const uint32_t nt = (uint32_t)c->nw * 64;
     *tiles_x = (d.astride + 127) / 128;
-    *nbins = *tiles_x * ((d.ah + 63) / 64);
+    *nbins = *tiles_x * ((d.ah + FL_TILE_H - 1) / FL_TILE_H);
     if (*nbins > 2047) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 2047 tiles of 128x64)", __FILE__, __LINE__);
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
     size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
-    if (lw > c->log_words) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(c->d_log); c->d_log = nullptr; c->log_words = 0;
-        HIPCHK(hipMalloc(&c->d_log, lw * 4));
-        c->log_words = lw;
+    if (lw > L(c).log_words) {
+        HIPCHK(hipStreamSynchronize(L(c).stream));
+        hipFree(L(c).d_log); L(c).d_log = nullptr; L(c).log_words = 0;
+        HIPCHK(hipMalloc(&L(c).d_log, lw * 4));
+        L(c).log_words = lw;
     }
-    if (dw > c->dir_words) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(c->d_dir); c->d_dir = nullptr; c->dir_words = 0;
-        HIPCHK(hipMalloc(&c->d_dir, dw * 4));
-        c->dir_words = dw;
+    if (dw > L(c).dir_words) {
+        HIPCHK(hipStreamSynchronize(L(c).stream));
+        hipFree(L(c).d_dir); L(c).d_dir = nullptr; L(c).dir_words = 0;
+        HIPCHK(hipMalloc(&L(c).d_dir, dw * 4));
+        L(c).dir_words = dw;
     }
     return FL_OK;
 }
@@ -369,15 +424,15 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         if (rc) return rc;
     }
     EvPair *e = ev_begin(c, c->iter_ev);
-    launch_iter(c->stream, c->nw, count, acc, c->nslots, g->d_prog, c->d_params, c->d_palette, c->d_rng, c->d_points,
-                c->d_hot, c->d_atom, (float *)c->d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
-                tiles_x, nbins, c->bin_rounds, nbatch_total, c->d_log, c->d_dir);
+    launch_iter(L(c).stream, c->nw, count, acc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
+                L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
+                tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir);
     ev_end(c, e);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
         EvPair *e2 = ev_begin(c, c->flush_ev);
-        launch_accum_tiles(c->stream, c->d_log, c->d_dir, c->d_palette, c->d_atom, (float *)c->d_front, tiles_x, nbins,
+        launch_accum_tiles(L(c).stream, L(c).d_log, L(c).d_dir, L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
                            c->bin_parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah);
         ev_end(c, e2);
         HIPCHK(hipGetLastError());
@@ -388,7 +443,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
 static int do_flush(fl_ctx *c, const fl_dim &d, bool use_hot = true)
 {
     EvPair *e = ev_begin(c, c->flush_ev);
-    launch_flush(c->stream, c->d_atom, c->d_front, c->d_hot, d.ah * d.astride, use_hot);
+    launch_flush(L(c).stream, L(c).d_atom, L(c).d_front, L(c).d_hot, d.ah * d.astride, use_hot);
     ev_end(c, e);
     HIPCHK(hipGetLastError());
     return FL_OK;
@@ -403,6 +458,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
+    if ((rc = wait_other(c, 1))) return rc;                 // walkers / RNG states are shared between lanes
     if ((rc = do_clear(c, d, true))) return rc;
     const uint32_t nt = (uint32_t)c->nw * 64;
     const double per_round = (double)c->nslots * nt;
@@ -423,6 +479,10 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
         batch += batch / 2;
         first = false;
     }
+    // the walkers are free once the last iterate kernel has run (the drain kernels that follow
+    // touch only this lane's buffers); record after everything queued so far on this stream
+    HIPCHK(hipEventRecord(L(c).ev_iter_done, L(c).stream));
+    L(c).iter_rec = true;
     return FL_OK;
 }
 
@@ -440,74 +500,74 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
-    hipStream_t st = c->stream;
+    hipStream_t st = L(c).stream;
     float k7[7];
     EvPair *e = ev_begin(c, c->filt_ev);
     switch (id) {
     case FL_FILT_YUV:
-        launch_yuv_to_rgb(st, d, c->d_back, c->d_front);
-        std::swap(c->d_front, c->d_back);
+        launch_yuv_to_rgb(st, d, L(c).d_back, L(c).d_front);
+        std::swap(L(c).d_front, L(c).d_back);
         break;
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
         if (getenv("FLAME_DE_REFERENCE_FORM")) {         // the literal per-tap form of the reference kernel
             for (int pat = 0; pat < 8; ++pat) {
-                launch_den_blur(st, d, c->d_blur, c->d_front, pat, 0, k7);
-                launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, pat, 1, k7);
-                launch_bilateral(st, d, c->d_back, c->d_front, (const float *)c->d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
-                std::swap(c->d_front, c->d_back);
+                launch_den_blur(st, d, L(c).d_blur, L(c).d_front, pat, 0, k7);
+                launch_den_blur_1c(st, d, (float *)L(c).d_side, L(c).d_blur, pat, 1, k7);
+                launch_bilateral(st, d, L(c).d_back, L(c).d_front, (const float *)L(c).d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
+                std::swap(L(c).d_front, L(c).d_back);
             }
             break;
         }
         // planes carved from the float4 side buffer: RA = 1/(avg+1e-6), Pa / Pb = w^dpow ping-pong
         const size_t nb = (size_t)d.ah * d.astride;
-        float *RA = (float *)c->d_side, *Pa = RA + nb, *Pb = Pa + nb;
-        float4 *Na = c->d_back, *Nb = c->d_front;
-        launch_de_prep(st, d, Na, Pa, c->d_front, p[3]);          // front(x,y,z,w) -> Na, Pa
+        float *RA = (float *)L(c).d_side, *Pa = RA + nb, *Pb = Pa + nb;
+        float4 *Na = L(c).d_back, *Nb = L(c).d_front;
+        launch_de_prep(st, d, Na, Pa, L(c).d_front, p[3]);          // front(x,y,z,w) -> Na, Pa
         for (int pat = 0; pat < 8; ++pat) {
-            launch_den_blur(st, d, c->d_blur, Na, pat, 0, k7);
-            launch_den_blur_1c_rcp(st, d, RA, c->d_blur, pat, 1, k7);
+            launch_den_blur(st, d, L(c).d_blur, Na, pat, 0, k7);
+            launch_den_blur_1c_rcp(st, d, RA, L(c).d_blur, pat, 1, k7);
             launch_de_bilateral(st, d, pat, Nb, Pb, Na, Pa, RA, p[0], p[1], p[2], p[3], p[4]);
             std::swap(Na, Nb); std::swap(Pa, Pb);
         }
         // 8 swaps: the result sits in Na == d_back; un-normalise it into d_front
-        launch_de_finish(st, d, c->d_front, Na);
+        launch_de_finish(st, d, L(c).d_front, Na);
     } break;
     case FL_FILT_LOGSCALE:
         REQUIRE(np >= 2, "logscale needs k1,k2");
-        launch_logscale(st, d, c->d_front, p[0], p[1]);
+        launch_logscale(st, d, L(c).d_front, p[0], p[1]);
         break;
     case FL_FILT_COLORCLIP:
         REQUIRE(np >= 5, "colorclip needs vib,highpow,gam,lin,lingam");
-        launch_colorclip(st, d, c->d_front, p[0], p[1], p[2], p[3], p[4]);
+        launch_colorclip(st, d, L(c).d_front, p[0], p[1], p[2], p[3], p[4]);
         break;
     case FL_FILT_SMEARCLIP:              // cuburn/filters.py:142-163
         REQUIRE(np >= 4, "smearclip needs width,gam_m_1,lin,lingam");
         gauss7(p[0], k7);
-        launch_gamma_full_hi(st, d, c->d_side, c->d_front);
-        launch_full_blur(st, d, c->d_back, c->d_side, 2, 0, k7);
-        launch_full_blur(st, d, c->d_side, c->d_back, 3, 0, k7);
-        launch_full_blur(st, d, c->d_back, c->d_side, 0, 0, k7);
-        launch_full_blur(st, d, c->d_side, c->d_back, 1, 0, k7);
-        launch_smearclip(st, d, c->d_front, c->d_side, p[1], p[2], p[3]);
+        launch_gamma_full_hi(st, d, L(c).d_side, L(c).d_front);
+        launch_full_blur(st, d, L(c).d_back, L(c).d_side, 2, 0, k7);
+        launch_full_blur(st, d, L(c).d_side, L(c).d_back, 3, 0, k7);
+        launch_full_blur(st, d, L(c).d_back, L(c).d_side, 0, 0, k7);
+        launch_full_blur(st, d, L(c).d_side, L(c).d_back, 1, 0, k7);
+        launch_smearclip(st, d, L(c).d_front, L(c).d_side, p[1], p[2], p[3]);
         break;
     case FL_FILT_HALOCLIP:               // cuburn/filters.py:113-130
         REQUIRE(np >= 1, "haloclip needs gam_m_1");
         gauss7(1.0f, k7);
-        launch_apply_gamma(st, d, c->d_blur, c->d_front, 0.1f);
-        launch_den_blur_1c(st, d, (float *)c->d_side, c->d_blur, 2, 0, k7);
-        launch_den_blur_1c(st, d, c->d_blur, (const float *)c->d_side, 3, 0, k7);
-        launch_haloclip(st, d, c->d_front, c->d_blur, p[0]);
+        launch_apply_gamma(st, d, L(c).d_blur, L(c).d_front, 0.1f);
+        launch_den_blur_1c(st, d, (float *)L(c).d_side, L(c).d_blur, 2, 0, k7);
+        launch_den_blur_1c(st, d, L(c).d_blur, (const float *)L(c).d_side, 3, 0, k7);
+        launch_haloclip(st, d, L(c).d_front, L(c).d_blur, p[0]);
         break;
     case FL_FILT_PLAINCLIP:
         REQUIRE(np >= 4, "plainclip needs gam_m_1,lin,lingam,brightness");
-        launch_plainclip(st, d, c->d_front, p[0], p[1], p[2], p[3]);
+        launch_plainclip(st, d, L(c).d_front, p[0], p[1], p[2], p[3]);
         break;
     case FL_FILT_LOGENCODE:
         REQUIRE(np >= 1, "logencode needs degamma");
-        launch_logencode(st, d, c->d_back, c->d_front, p[0]);
-        std::swap(c->d_front, c->d_back);
+        launch_logencode(st, d, L(c).d_back, L(c).d_front, p[0]);
+        std::swap(L(c).d_front, L(c).d_back);
         break;
     default:
         return fail(FL_E_UNSUPPORTED, "unknown filter id", __FILE__, __LINE__);
@@ -524,11 +584,15 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
-    void *dst = dev_out ? (void *)(uintptr_t)dev_out : c->d_outpix;
-    launch_f32_to_rgba(c->stream, d, c->d_front, c->d_rng, c->nslots * (uint32_t)c->nw * 64, fmt, dst);
+    void *dst = dev_out ? (void *)(uintptr_t)dev_out : L(c).d_outpix;
+    { int rc2 = wait_other(c, 2); if (rc2) return rc2; }   // the dither RNG states are shared between lanes
+    fl_mwc *rng_out = c->d_rng + (size_t)c->nslots * c->nw * 64 + FL_PAL_H * 256;
+    launch_f32_to_rgba(L(c).stream, d, L(c).d_front, rng_out, FL_NOUT, fmt, dst);
     HIPCHK(hipGetLastError());
-    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
-    if (c->frame_seq) HIPCHK(hipEventRecord(c->ev_end_[(c->frame_seq - 1) % fl_ctx::kFrames], c->stream));
+    HIPCHK(hipEventRecord(L(c).ev_out_done, L(c).stream));
+    L(c).out_rec = true;
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, L(c).stream));
+    if (c->frame_seq) HIPCHK(hipEventRecord(c->ev_end_[(c->frame_seq - 1) % fl_ctx::kFrames], L(c).stream));
     return FL_OK;
 }
 
@@ -571,7 +635,7 @@ static float sum_ms(std::vector<EvPair> &v)
 int fl_timings_reset(fl_ctx *c)
 {
     REQUIRE(c, "null ctx");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sync_all(c);
     c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
     return FL_OK;
 }
@@ -579,7 +643,7 @@ int fl_timings_reset(fl_ctx *c)
 int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *nlaunch)
 {
     REQUIRE(c, "null ctx");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sync_all(c);
     if (iter_ms) *iter_ms = sum_ms(c->iter_ev);
     if (flush_ms) *flush_ms = sum_ms(c->flush_ev);
     if (filter_ms) *filter_ms = sum_ms(c->filt_ev);
@@ -590,15 +654,15 @@ int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uin
 static int buf_ptr(fl_ctx *c, fl_genome *g, int which, void **p, size_t *cap)
 {
     switch (which) {
-    case FL_BUF_FRONT: *p = c->d_front; *cap = 16 * c->nbins; break;
-    case FL_BUF_BACK: *p = c->d_back; *cap = 16 * c->nbins; break;
-    case FL_BUF_SIDE: *p = c->d_side; *cap = 16 * c->nbins; break;
-    case FL_BUF_PARAMS: *p = c->d_params; *cap = 4 * (size_t)FL_NTEMPORAL * (g ? g->pstride : FL_MAX_PSTRIDE); break;
-    case FL_BUF_PALETTE: *p = c->d_palette; *cap = 8 * FL_PAL_H * FL_PAL_W; break;
+    case FL_BUF_FRONT: *p = L(c).d_front; *cap = 16 * L(c).nbins; break;
+    case FL_BUF_BACK: *p = L(c).d_back; *cap = 16 * L(c).nbins; break;
+    case FL_BUF_SIDE: *p = L(c).d_side; *cap = 16 * L(c).nbins; break;
+    case FL_BUF_PARAMS: *p = L(c).d_params; *cap = 4 * (size_t)FL_NTEMPORAL * (g ? g->pstride : FL_MAX_PSTRIDE); break;
+    case FL_BUF_PALETTE: *p = L(c).d_palette; *cap = 8 * FL_PAL_H * FL_PAL_W; break;
     case FL_BUF_POINTS: *p = c->d_points; *cap = 16 * (size_t)c->nslots * c->nw * 64; break;
     case FL_BUF_SEEDS: *p = c->d_rng; *cap = sizeof(fl_mwc) * (size_t)c->nwalkers; break;
-    case FL_BUF_ATOM: *p = c->d_atom; *cap = 8 * c->nbins; break;
-    case FL_BUF_HOT: *p = c->d_hot; *cap = 4 * (c->nbins / 16); break;
+    case FL_BUF_ATOM: *p = L(c).d_atom; *cap = 8 * L(c).nbins; break;
+    case FL_BUF_HOT: *p = L(c).d_hot; *cap = 4 * (L(c).nbins / 16); break;
     default: return fail(FL_E_INVAL, "unknown buffer", __FILE__, __LINE__);
     }
     if (!*p) return fail(FL_E_INVAL, "buffer not allocated yet", __FILE__, __LINE__);
@@ -612,7 +676,7 @@ int fl_read_buffer(fl_ctx *c, fl_genome *g, int which, void *dst, size_t nbytes)
     int rc = buf_ptr(c, g, which, &p, &cap);
     if (rc) return rc;
     REQUIRE(nbytes <= cap, "read larger than buffer");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sync_all(c);
     HIPCHK(hipMemcpy(dst, p, nbytes, hipMemcpyDeviceToHost));
     return FL_OK;
 }
@@ -624,7 +688,7 @@ int fl_write_buffer(fl_ctx *c, fl_genome *g, int which, const void *src, size_t 
     int rc = buf_ptr(c, g, which, &p, &cap);
     if (rc) return rc;
     REQUIRE(nbytes <= cap, "write larger than buffer");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sync_all(c);
     HIPCHK(hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice));
     return FL_OK;
 }
@@ -648,7 +712,7 @@ int fl_debug_iter_launch(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, uint32
     int rc = ensure_fb(c, d);
     if (rc) return rc;
     c->round_counter = round0;
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, L(c).stream));
     return do_iter_launch(c, g, d, nrounds, fuse, true, accum_mode);
 }
 
@@ -663,9 +727,9 @@ int fl_debug_flush(fl_ctx *c, uint32_t w, uint32_t h)
 
 int fl_debug_clear_hot(fl_ctx *c, uint32_t w, uint32_t h)
 {
-    REQUIRE(c && c->d_hot, "null ctx");
+    REQUIRE(c && L(c).d_hot, "null ctx");
     fl_dim d; fl_calc_dim(w, h, &d);
-    HIPCHK(hipMemsetAsync(c->d_hot, 0, 4 * ((size_t)d.ah * d.astride / 16), c->stream));
+    HIPCHK(hipMemsetAsync(L(c).d_hot, 0, 4 * ((size_t)d.ah * d.astride / 16), L(c).stream));
     return FL_OK;
 }
 
@@ -675,8 +739,8 @@ int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)
     HIPCHK(hipSetDevice(c->device));
     uint32_t *d; const size_t n = (size_t)c->nw * 64;
     HIPCHK(hipMalloc(&d, 4 * n));
-    launch_shuffle_tap(c->stream, c->nw, d, round);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    launch_shuffle_tap(L(c).stream, c->nw, d, round);
+    HIPCHK(hipStreamSynchronize(L(c).stream));
     HIPCHK(hipMemcpy(out256, d, 4 * n, hipMemcpyDeviceToHost));
     hipFree(d);
     return FL_OK;
@@ -692,8 +756,8 @@ int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n,
     HIPCHK(hipMalloc(&dr, sizeof(fl_mwc) * (size_t)n));
     HIPCHK(hipMemcpy(dp, xyzw, 16 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, rng, sizeof(fl_mwc) * (size_t)n, hipMemcpyHostToDevice));
-    launch_apply_xf_tap(c->stream, g->d_prog, c->d_params, ts, xfi, n, dp, dr);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    launch_apply_xf_tap(L(c).stream, g->d_prog, L(c).d_params, ts, xfi, n, dp, dr);
+    HIPCHK(hipStreamSynchronize(L(c).stream));
     HIPCHK(hipMemcpy(xyzw, dp, 16 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rng, dr, sizeof(fl_mwc) * (size_t)n, hipMemcpyDeviceToHost));
     hipFree(dp); hipFree(dr);
@@ -703,7 +767,7 @@ int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n,
 int fl_debug_counters(fl_ctx *c, uint64_t out4[4])
 {
     REQUIRE(c && out4, "null argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sync_all(c);
     HIPCHK(hipMemcpy(out4, c->d_counters, 32, hipMemcpyDeviceToHost));
     return FL_OK;
 }

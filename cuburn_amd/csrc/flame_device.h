@@ -68,9 +68,12 @@ __device__ __forceinline__ uint32_t trunca(float f) {
 
 // ---- binned accumulate geometry: 128 x 64 pixel tiles; record = {bin 11 | ly 6 | lx 7 | ci 8} --------
 #define FL_TILE_W 128u
-#define FL_TILE_H 64u
+#ifndef FL_TILE_H_LOG2
+#define FL_TILE_H_LOG2 6u
+#endif
+#define FL_TILE_H (1u << FL_TILE_H_LOG2)
 #define FL_TILE_CELLS (FL_TILE_W * FL_TILE_H)
-#define FL_REC_BITS 21u                      /* ly 6 + lx 7 + ci 8 */
+#define FL_REC_BITS (15u + FL_TILE_H_LOG2)   /* ly + lx 7 + ci 8 */
 #define FL_MAX_BINS 2047u
 
 // XCD id of the executing workgroup (HW_REG_XCC_ID, bits [3:0])

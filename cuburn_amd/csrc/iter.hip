@@ -238,8 +238,8 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         } else if (ACC == 1) {
             // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
             // and written to this slot's private region of the sample log (no global atomics)
-            const uint32_t bin = ok ? (iy >> 6) * bg.tiles_x + (ix >> 7) : bg.nbins;
-            const uint32_t rec = (bin << FL_REC_BITS) | ((iy & 63u) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
+            const uint32_t bin = ok ? (iy >> FL_TILE_H_LOG2) * bg.tiles_x + (ix >> 7) : bg.nbins;
+            const uint32_t rec = (bin << FL_REC_BITS) | ((iy & (FL_TILE_H - 1u)) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (++staged == bg.rounds || rd + 1 == nrounds) {

@@ -67,7 +67,8 @@ class Framebuffers(object):
         self.nslots = nslots
         self.nw = 8 if os.environ.get('FLAME_NW') == '8' else 4       # waves per iterate workgroup
         self.nthreads = self.nw * 64
-        self.nwalkers = nslots * self.nthreads + 64 * 256
+        self.nout = 65536                   # RNG states of the output dither kernel
+        self.nwalkers = nslots * self.nthreads + 64 * 256 + self.nout
         seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, host_seed))
         ctx = C.c_void_p()
         _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, self.nwalkers, nslots, C.byref(ctx)))

@@ -137,8 +137,12 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
 /* cuburn/render.py:253-262 RenderManager.__init__ + :91-104 Framebuffers.__init__:
  * device, streams, walker/RNG state (persistent across frames, render.py:95-104).
  * `seeds` = nseeds x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
- * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 with NW = waves per iterate workgroup
- * (4; 8 when the environment says FLAME_NW=8).  stream = hipStream_t or NULL. */
+ * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536 with NW = waves per iterate workgroup
+ * (4; 8 when the environment says FLAME_NW=8): walkers, then the palette kernel's states, then
+ * the output dither's.  stream = a hipStream_t to run everything on (single lane), or NULL:
+ * the context then owns two streams and alternates consecutive frames between them so that the
+ * drain / filter / output work of frame k overlaps the iteration of frame k+1
+ * (cuburn/render.py:432-433 swaps stream_a / stream_b the same way). */
 int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out);
 void fl_ctx_destroy(fl_ctx *ctx);
 int fl_ctx_sync(fl_ctx *ctx);

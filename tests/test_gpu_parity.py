@@ -373,11 +373,15 @@ def test_output_bit_exact(mgr, fmt):
     buf = rs.uniform(-0.2, 1.3, (dim.ah * dim.astride, 4)).astype(np.float32)
     _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 0))
     mgr.fb.write('front', buf)
-    seeds = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
+    seeds = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
     out = np.zeros((FH, FW, 4), np.uint16 if fmt else np.uint8)
     _lib.check(lib.fl_output(mgr.fb.ctx, FW, FH, fmt, out.ctypes.data, 0))
     _lib.check(lib.fl_ctx_sync(mgr.fb.ctx))
-    ref, rng_after = O.f32_to_rgba(d, buf, seeds[:NSLOTS * 256], fmt)
+    # the dither kernel owns the last 65536 RNG states (walkers | palette rows | output dither)
+    ref, rng_after = O.f32_to_rgba(d, buf, seeds[(NSLOTS + 64) * 256:], fmt)
+    assert len(seeds) - (NSLOTS + 64) * 256 == mgr.fb.nout
+    after = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
+    assert np.array_equal(after[(NSLOTS + 64) * 256:], rng_after)
     assert np.array_equal(out, ref)
     # cuburn/code/tests/test_output.py ranges: negative -> 0, >1 -> peak
     peak = 65535 if fmt else 255
