@@ -406,3 +406,83 @@ def test_queue_frame_end_to_end(mgr):
     assert t['iter_ms'] > 0 and t['filter_ms'] > 0
     media, logs = rdr.out.encode(h_out)
     assert media
+
+
+# ---------------------------------------------------------------------------------- larger configs
+def test_cfg3_animated_distribution(mgr):
+    """cfg3: 8 xforms + final xform, two interpolated palettes, temporal sampling over the frame
+    window (td > 0: 1024 different parameter blocks, 64 palette rows) against the flam3-style game
+    driven by the oracle's own parameter blocks and palette."""
+    gnm, prof = small(configs.cfg3, 480, 270, samples=2 ** 26)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    dim = mgr.fb.calc_dim(gprof.width, gprof.height)
+    lib = _lib.load()
+    tc = 0.37
+    ts, td = frame_times(gprof, tc)
+    assert td > 0
+    _lib.check(lib.fl_interp(mgr.fb.ctx, g, dim.w, dim.h, ts, td))
+    run = C.c_uint64()
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 26), 64, 1, C.byref(run)))
+    nbins = dim.ah * dim.astride
+    front = mgr.fb.read('front', (nbins, 4), np.float32)
+    F = prepare(gnm, prof, tc)
+    ref, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], 2 ** 26, 8)
+    dg, dr = density(front, dim), density(ref, dim)
+    assert abs(dg.sum() / run.value - dr.sum() / 2 ** 26) < 3e-3
+    H, W = dim.ah // 8 * 8, dim.astride // 8 * 8
+    bg = dg[:H, :W].reshape(H // 8, 8, W // 8, 8).sum((1, 3))
+    br = dr[:H, :W].reshape(H // 8, 8, W // 8, 8).sum((1, 3))
+    assert np.abs(bg / bg.sum() - br / br.sum()).sum() < 0.025
+    cg = front[:, :3].sum(0) / dg.sum()
+    cr = ref[:, :3].sum(0) / dr.sum()
+    assert np.abs(cg - cr).max() < 1.5 / 255, (cg, cr)
+
+
+def test_4k_binned_equals_atomic(mgr):
+    """3840x2160 (1085 tiles of 128x64): binned and direct-atomic accumulate agree bit for bit."""
+    gnm, prof = linear_flame()
+    prof = dict(prof, width=3840, height=2160)
+    gnm['camera']['scale'] = 0.6
+    res_a, _, dev_a, dim, seeds = run_device_model_gpu_only(mgr, gnm, prof, nrounds=13, fuse=5, mode=0)
+    res_b, _, dev_b, dim, _ = run_device_model_gpu_only(mgr, gnm, prof, nrounds=13, fuse=5, mode=1, seeds_in=seeds)
+    assert np.array_equal(res_a['ctr'][:2], res_b['ctr'][:2])
+    assert int(res_a['ctr'][3]) == 0
+    assert np.array_equal(res_a['atom'], res_b['atom'])
+    assert int((res_a['atom'] >> np.uint64(54)).sum()) == int(res_a['ctr'][0])
+    assert np.array_equal(dev_a, dev_b)
+
+
+def run_device_model_gpu_only(mgr, gnm, prof, nrounds, fuse, mode, seeds_in=None):
+    lib = _lib.load()
+    if seeds_in is not None:
+        mgr.fb.write('seeds', seeds_in)
+    seeds0 = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
+    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof)
+    nbins = dim.ah * dim.astride
+    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 1))
+    _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, 0, nrounds + fuse, fuse, mode))
+    ctr = np.zeros(4, np.uint64)
+    _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr.ctypes.data))
+    atom = mgr.fb.read('atom', (nbins,), np.uint64)
+    rng = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)[:NSLOTS * 256]
+    return dict(ctr=ctr, atom=atom), None, rng, dim, seeds0
+
+
+def test_8k_uses_direct_atomics(mgr):
+    """7680x4320 has 4148 tiles (> 2047): the binned mode refuses it, the shim's 'auto' picks atomics."""
+    lib = _lib.load()
+    gnm, prof = linear_flame()
+    prof = dict(prof, width=7680, height=4320)
+    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof)
+    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 1))
+    rc = lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, 0, 8, 4, 1)
+    assert rc == _lib.FL_E_UNSUPPORTED
+    _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, 0, 8, 4, 0))
+    ctr = np.zeros(4, np.uint64)
+    _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr.ctypes.data))
+    assert int(ctr[0]) + int(ctr[1]) == NSLOTS * 256 * 4
+    atom = mgr.fb.read('atom', (dim.ah * dim.astride,), np.uint64)
+    assert int((atom >> np.uint64(54)).sum()) == int(ctr[0])
