@@ -93,16 +93,22 @@ struct BinGeom {
     uint32_t nbins;          // number of tiles B (<= FL_MAX_BINS)
     uint32_t rounds;         // R: write-enabled rounds per batch
     uint32_t nbatch_total;   // batches of this launch = nslots * batches per slot
-    uint32_t *log;           // [nbatch_total * R * NT] sorted records
-    uint32_t *dir;           // [B][nbatch_total] (first record << 16) | count
 };
+// log: [nbatch_total * R * NT] sorted records; dir: [B][nbatch_total] (first record << 16) | count.
+// They are separate __restrict__ kernel arguments: as members of the struct the compiler has to
+// assume their stores may alias the parameter block, and every (wave-uniform) parameter load in
+// the loop stops being an s_load.
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += t;
-    }
+// Inclusive add-scan over the 64 lanes with DPP (pure VALU: row_shr 1/2/4/8 inside each row of
+// 16, then row_bcast:15 / row_bcast:31 carry the row totals) — ~10 instructions; the __shfl_up
+// form is six ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return v;
 }
 
@@ -114,7 +120,8 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
        const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points,
        const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4,
        u64 *__restrict__ counters, uint32_t astride, uint32_t aheight,
-       uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg)
+       uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg,
+       uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir)
 {
     constexpr int NT = NW * 64;
     // all LDS is carved from the dynamic region (16-byte aligned pieces)
@@ -194,9 +201,13 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
             const uint32_t par = rd & 1u, dst = phase == 0 ? dst0 : (phase == 1 ? dst1 : dst2);
+#ifndef ABL_NOSWAP
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+#else
+            (void)par; (void)dst;
+#endif
             phase = phase == 2 ? 0 : phase + 1;
         }
         if (rd < fuse) continue;                                            // iter.py:298-300
@@ -240,9 +251,20 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
             // and written to this slot's private region of the sample log (no global atomics)
             const uint32_t bin = ok ? (iy >> FL_TILE_H_LOG2) * bg.tiles_x + (ix >> 7) : bg.nbins;
             const uint32_t rec = (bin << FL_REC_BITS) | ((iy & (FL_TILE_H - 1u)) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
+#ifdef ABL_NOSTAGE
+            if (rec == 0x12345678u) stage[tid] = rec;
+            continue;
+#endif
             stage[staged * NT + tid] = rec;
+#ifndef ABL_NOCNT
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#ifdef ABL_NOFLUSH
+            if (++staged == bg.rounds) staged = 0;
+            if (false) {
+#else
             if (++staged == bg.rounds || rd + 1 == nrounds) {
+#endif
                 const uint32_t n = staged * NT;
                 const uint32_t batch_id = batch_in_slot * gridDim.x + slot;
                 __syncthreads();
@@ -254,20 +276,33 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                         const uint32_t incl = wave_incl_scan(v, l);
                         const uint32_t excl = incl - v + running;
                         if (b <= bg.nbins) { cur[b] = excl; cnt[b] = 0; }
-                        if (b < bg.nbins) bg.dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+#ifdef ABL_DIRBM
+                        if (b < bg.nbins) bin_dir[(size_t)batch_id * bg.nbins + b] = (excl << 16) | v;
+#else
+                        if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+#endif
                         if (b == bg.nbins) *s_nvalid = excl;
-                        running += __shfl(incl, 63);
+                        running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     }
                 }
                 __syncthreads();
-                for (uint32_t i = tid; i < n; i += NT) {
-                    const uint32_t r2 = stage[i];
-                    const uint32_t pos = __hip_atomic_fetch_add(cur + (r2 >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    sorted[pos] = r2 & ((1u << FL_REC_BITS) - 1u);
+                // scatter, four records per thread in flight (the returning LDS atomic is a
+                // ~100-cycle round trip; one at a time this loop was a quarter of the kernel)
+                for (uint32_t i0 = 0; i0 < n; i0 += 4 * NT) {
+                    uint32_t r2[4], pos[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * NT + tid; r2[q] = i < n ? stage[i] : 0xffffffffu; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r2[q] != 0xffffffffu)
+                            pos[q] = __hip_atomic_fetch_add(cur + (r2[q] >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r2[q] != 0xffffffffu) sorted[pos[q]] = r2[q] & ((1u << FL_REC_BITS) - 1u);
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;
-                uint4 *dst = reinterpret_cast<uint4 *>(bg.log + (size_t)batch_id * bg.rounds * NT);
+                uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
                 const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
                 staged = 0; ++batch_in_slot;
@@ -375,13 +410,13 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
                  uint32_t *log, uint32_t *dir)
 {
-    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, log, dir};
+    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total};
     const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins);
 #define LAUNCH(NW, C, A) do { \
         static bool attr_done = false; \
         if (!attr_done) { hipFuncSetAttribute((const void *)k_iter<NW, C, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         hipLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, prog, params, palette, \
-        rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg); } while (0)
+        rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg, log, dir); } while (0)
     if (acc == 2) { if (nw == 4) LAUNCH(4, false, 2); else LAUNCH(8, false, 2); }
     else if (acc == 1) {
         if (nw == 4) { if (count) LAUNCH(4, true, 1); else LAUNCH(4, false, 1); }
