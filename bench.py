@@ -71,6 +71,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (0 = skip)')
+    ap.add_argument('--shard', default='frames', choices=['frames', 'samples'],
+                    help="multi-GPU split: whole frames per rank (default, weak scaling, the reference's "
+                         "distribute.py model) or the samples of each single frame with one RCCL "
+                         "all-reduce of the accumulators (strong scaling; for frames like cfg5)")
     ap.add_argument('--accum', default=os.environ.get('FLAME_ACCUM', 'binned'), choices=['binned', 'atomic'])
     args = ap.parse_args()
 
@@ -86,7 +90,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     torch.cuda.set_device(local)
 
-    from cuburn_amd import configs, profile, render, _lib
+    from cuburn_amd import configs, profile, render, _lib, distributed as D
     gnm, prof = configs.CONFIGS[args.config]()
     gprof = profile.wrap(prof, gnm)
     mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1024)), host_seed=42 + rank)
@@ -108,6 +112,11 @@ def main():
 
     def run(nframes):
         """The double-buffered frame loop of the reference (main.py:64-76): queue frame k+1, then wait for frame k."""
+        if args.shard == 'samples':
+            for _ in range(nframes):
+                evt, _h = D.queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=local)
+                evt.synchronize()
+            return
         pending = None
         for _ in range(nframes):
             nxt = mgr.queue_frame(rdr, gnm, gprof, tc)
@@ -152,11 +161,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    job_samples_per_step = mgr.last_nsamples * world            # frames: every rank runs the same workload
+    if world > 1 and args.shard == 'samples':
+        ns = torch.tensor([mgr.last_nsamples], dtype=torch.float64, device='cuda')
+        dist.all_reduce(ns)
+        job_samples_per_step = int(ns.item())
 
     if rank == 0:
         dim = render.Framebuffers.calc_dim(w, h)
         nbins = dim.ah * dim.astride
-        samples_total = mgr.last_nsamples * args.steps * world    # every rank runs the same workload
+        samples_total = job_samples_per_step * args.steps
         iter_s = acc['iter_ms'] * 1e-3
         achieved = 16.0 * acc['samples'] / iter_s / 1e9 if iter_s > 0 else 0.0
         pipe_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
@@ -177,13 +191,13 @@ def main():
             'unit': 'Msamples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frames' else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
                        'samples_per_frame': mgr.last_nsamples, 'stream_lanes': 2,
                        'accum': args.accum, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
-                       'parallelism': 'frame-sharded x%d, RCCL gather' % world},
+                       'parallelism': ('frame-sharded x%d, RCCL gather' if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators') % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'pipeline': {'kernels': 'k_iter+k_accum_tiles+k_flush', 'achieved': round(pipe, 2), 'frac': round(pipe / HBM_PEAK_GBS, 5)},

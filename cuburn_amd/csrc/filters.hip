@@ -266,7 +266,7 @@ k_de_bilateral(fl_dim d, float4 *__restrict__ Nout, float *__restrict__ Pout,
     // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the 1/weightsum
     // of the reference cancels), the density is out.w / (weightsum + 1e-10)
     const float wn = out.w * frcp(weightsum + 1e-10f);
-    const float rn = out.w > 0.0f ? frcp(out.w) : 0.0f;
+    const float rn = out.w >= 1.17549435e-38f ? frcp(out.w) : 0.0f;   // v_rcp_f32 of a denormal is +inf
     Nout[gi] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
     Pout[gi] = fpow(wn, dpow);
 }
@@ -405,7 +405,7 @@ k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRo
         // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the
         // 1/weightsum of the reference cancels), the density is out.w / (weightsum + 1e-10)
         const float wn = out.w * frcp(weightsum + 1e-10f);
-        const float rn = out.w > 0.0f ? frcp(out.w) : 0.0f;
+        const float rn = out.w >= 1.17549435e-38f ? frcp(out.w) : 0.0f;   // v_rcp_f32 of a denormal is +inf
         const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox);
         Nout[go] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
         PRout[go].x = fpow(wn, dpow);

@@ -696,6 +696,15 @@ int fl_read_buffer(fl_ctx *c, fl_genome *g, int which, void *dst, size_t nbytes)
     return FL_OK;
 }
 
+int fl_buffer_ptr(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size_t *nbytes)
+{
+    REQUIRE(c && dev_ptr && nbytes, "null argument");
+    int rc = buf_ptr(c, g, which, dev_ptr, nbytes);
+    if (rc) return rc;
+    sync_all(c);
+    return FL_OK;
+}
+
 int fl_write_buffer(fl_ctx *c, fl_genome *g, int which, const void *src, size_t nbytes)
 {
     REQUIRE(c && src, "null argument");

@@ -6,7 +6,15 @@ animation are independent, so rank r renders frames r, r+world, r+2*world, ... w
 exchange in the data path; finished 8/16-bit frames are gathered to rank 0 with one
 collective per round of frames (RCCL over xGMI when the backend is "nccl"; the same code
 runs on "gloo" for the CPU tests).
+
+A single large frame can instead be sharded by SAMPLES: every rank iterates
+``nsamples/world`` samples with its own RNG streams into its own accumulator, the float4
+accumulators are summed with one all-reduce (the only exchange of the path: 16 B x nbins, e.g.
+537 MB at 8K, ~7 links x 153 GB/s of xGMI per GPU), and the filter chain runs on the sum.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -52,3 +60,91 @@ def gather_animation(local_frames, nframes, dst=0):
                 if idx < nframes:
                     result[idx] = t
     return result
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def rank_seed(host_seed, rank=None):
+    """
+    Host seed of a rank's RNG table for sample-sharded rendering.  mwc.make_seeds(n, seed) draws
+    the (multiplier, state, carry) rows from RandomState(seed) (mwc.py:30-47): different seeds
+    give every rank different streams.  Rank 0 keeps ``host_seed`` so that a world of 1 is the
+    unsharded render.
+    """
+    if rank is None:
+        rank = _world()[0]
+    base = 42 if host_seed is None else int(host_seed)
+    return base + 7919 * rank
+
+
+def sample_share(nsamples, rank=None, world=None):
+    """This rank's share of a frame's samples; shares differ by at most 1 and sum to nsamples."""
+    if world is None:
+        rank, world = _world()
+    nsamples = int(nsamples)
+    return nsamples // world + (1 if rank < nsamples % world else 0)
+
+
+def sum_accumulators(acc):
+    """All-reduce (sum) one accumulator tensor in place across ranks; no-op when not distributed."""
+    if _world()[1] > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    return acc
+
+
+class _DeviceArray(object):
+    """Zero-copy view of a device buffer of the native context for torch (CUDA array interface)."""
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = dict(shape=(int(nfloats),), typestr='<f4',
+                                             data=(int(ptr), False), version=2)
+
+
+def accumulator_tensor(fb, device):
+    """The float4[nbins] accumulator of the current frame as a flat float32 torch tensor."""
+    from . import _lib
+    p, n = C.c_void_p(), C.c_size_t()
+    _lib.check(_lib.load().fl_buffer_ptr(fb.ctx, None, _lib.BUF['front'], C.byref(p), C.byref(n)))
+    return torch.as_tensor(_DeviceArray(p.value, n.value // 4), device=torch.device('cuda', device))
+
+
+def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True):
+    """
+    RenderManager.queue_frame for ONE frame split by samples over all ranks.  Every rank must
+    call it (it contains the collective) with a RenderManager built with
+    ``host_seed=rank_seed(seed)``; every rank ends up with the finished frame.
+    Returns ``(evt, h_out)`` like queue_frame (cuburn/render.py:374-434).
+    """
+    from . import _lib
+    from .render import DurationEvent
+    lib = _lib.load()
+    rank, world = _world()
+    if device is None:
+        device = torch.cuda.current_device()
+    fb = mgr.fb
+    dim = fb.set_dim(gprof.width, gprof.height)
+    td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
+    ts = tc - 0.5 * td
+    g = rdr._handle(fb)
+    fid = C.c_uint32()
+    _lib.check(lib.fl_frame_begin(fb.ctx, C.byref(fid)))
+    if copy:
+        mgr._copy(rdr, gnm)
+    _lib.check(lib.fl_interp(fb.ctx, g, dim.w, dim.h, ts, td))
+    nsamps = sample_share(gprof.spp(tc) * dim.w * dim.h, rank, world)
+    run = C.c_uint64()
+    _lib.check(lib.fl_iterate(fb.ctx, g, dim.w, dim.h, float(nsamps), mgr.fuse,
+                              mgr.resolve_accum_mode(dim), C.byref(run)))
+    mgr.last_nsamples = run.value
+    if world > 1:
+        acc = accumulator_tensor(fb, device)      # waits for the iterate + flush kernels
+        sum_accumulators(acc)
+        torch.cuda.synchronize(device)
+    for filt in rdr.filts:
+        filt.apply(fb, gprof, getattr(gprof.filters, filt.name), dim, tc)
+    rdr.out.convert(fb, gprof, dim)
+    h_out = rdr.out.copy(fb, dim)
+    return DurationEvent(fb.ctx, fid.value), h_out

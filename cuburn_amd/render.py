@@ -190,6 +190,13 @@ class RenderManager(object):
                                                 knots.ctypes.data, palettes.ctypes.data,
                                                 palette_times.ctypes.data, len(ptimes)))
 
+    def resolve_accum_mode(self, dim):
+        mode = self.accum_mode
+        if mode == 'auto':
+            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
+            mode = _lib.ACCUM_BINNED if ntiles <= 2047 else _lib.ACCUM_ATOMIC
+        return mode
+
     def queue_frame(self, rdr, gnm, gprof, tc, copy=True):
         """
         Queue one frame at centre time ``tc``; returns ``(evt, h_out)`` (render.py:374-434).
@@ -206,11 +213,8 @@ class RenderManager(object):
         _lib.check(lib.fl_interp(self.fb.ctx, g, dim.w, dim.h, ts, td))
         nsamps = gprof.spp(tc) * dim.w * dim.h
         run = C.c_uint64()
-        mode = self.accum_mode
-        if mode == 'auto':
-            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
-            mode = _lib.ACCUM_BINNED if ntiles <= 2047 else _lib.ACCUM_ATOMIC
-        _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse, mode, C.byref(run)))
+        _lib.check(lib.fl_iterate(self.fb.ctx, g, dim.w, dim.h, float(nsamps), self.fuse,
+                                  self.resolve_accum_mode(dim), C.byref(run)))
         self.last_nsamples = run.value
         for filt in rdr.filts:
             params = getattr(gprof.filters, filt.name)

@@ -229,6 +229,14 @@ enum {
 int fl_read_buffer(fl_ctx *ctx, fl_genome *g, int which, void *host_dst, size_t nbytes);
 int fl_write_buffer(fl_ctx *ctx, fl_genome *g, int which, const void *host_src, size_t nbytes);
 
+/* Device address and size of one of the buffers above (current frame's lane), after waiting for
+ * all queued work of the context.  This is the hook for the one exchange step of sample-sharded
+ * rendering of a single frame: every rank iterates its share of the samples,
+ * the caller sums FL_BUF_FRONT across ranks with its own collective (RCCL all-reduce on its own
+ * stream), synchronises that stream, and continues with fl_filter / fl_output.  The reference has
+ * no such step (distribute.py:149-163 shards whole frames only). */
+int fl_buffer_ptr(fl_ctx *ctx, fl_genome *g, int which, void **dev_ptr, size_t *nbytes);
+
 /* Single-launch taps for bit-exact tests: run `nrounds` rounds (first `fuse` write-disabled)
  * for every slot with the given global round counter, no clears, no flush. */
 int fl_debug_iter_launch(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, uint32_t round0,

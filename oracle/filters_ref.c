@@ -13,6 +13,27 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+
+/* The reference compiles its kernels with -use_fast_math (cuburn/code/util.py:96), which implies
+ * -ftz=true: float denormals are read as zero and flushed on output.  That matters in the DE
+ * chain, whose weights underflow on sparse images: with denormals kept, `pix.w > 0` holds for a
+ * 1e-40 density whose reciprocal is +inf and the colour terms turn into NaN.  Every public entry
+ * point below therefore runs with the SSE FTZ and DAZ modes set (and restores the caller's). */
+typedef struct { unsigned ftz, daz; } fz_state;
+static fz_state fz_enter(void)
+{
+    fz_state s = { _MM_GET_FLUSH_ZERO_MODE(), _MM_GET_DENORMALS_ZERO_MODE() };
+    _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+    _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+    return s;
+}
+static void fz_leave(fz_state s)
+{
+    _MM_SET_FLUSH_ZERO_MODE(s.ftz);
+    _MM_SET_DENORMALS_ZERO_MODE(s.daz);
+}
 
 #define RM_SQRT2 1.41421353816986f
 
@@ -37,7 +58,7 @@ static inline size_t shear_idx(const ref_dim *d, int pattern, int x, int y, floa
 }
 
 /* cuburn/code/color.py:25-40 + cuburn/code/filters.py:71-77 */
-void ref_yuv_to_rgb(const ref_dim *d, float *dst, const float *src)
+static void ref_yuv_to_rgb_impl(const ref_dim *d, float *dst, const float *src)
 {
     size_t n = (size_t)d->ah * d->astride;
     for (size_t i = 0; i < n; ++i) {
@@ -52,7 +73,7 @@ void ref_yuv_to_rgb(const ref_dim *d, float *dst, const float *src)
 }
 
 /* cuburn/code/filters.py:106-117 */
-void ref_den_blur(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
+static void ref_den_blur_impl(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
 {
     for (int y = 0; y < (int)d->ah; ++y)
         for (int x = 0; x < (int)d->astride; ++x) {
@@ -64,7 +85,7 @@ void ref_den_blur(const ref_dim *d, float *dst, const float *src4, int pattern, 
 }
 
 /* cuburn/code/filters.py:120-131 */
-void ref_den_blur_1c(const ref_dim *d, float *dst, const float *src1, int pattern, int upsample, const float *coefs)
+static void ref_den_blur_1c_impl(const ref_dim *d, float *dst, const float *src1, int pattern, int upsample, const float *coefs)
 {
     for (int y = 0; y < (int)d->ah; ++y)
         for (int x = 0; x < (int)d->astride; ++x) {
@@ -76,7 +97,7 @@ void ref_den_blur_1c(const ref_dim *d, float *dst, const float *src1, int patter
 }
 
 /* cuburn/code/filters.py:136-151 */
-void ref_full_blur(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
+static void ref_full_blur_impl(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
 {
     for (int y = 0; y < (int)d->ah; ++y)
         for (int x = 0; x < (int)d->astride; ++x) {
@@ -90,7 +111,7 @@ void ref_full_blur(const ref_dim *d, float *dst, const float *src4, int pattern,
 }
 
 /* cuburn/code/filters.py:166-264 */
-void ref_bilateral(const ref_dim *d, float *dst, const float *src4, const float *blur1, int pattern, int radius,
+static void ref_bilateral_impl(const ref_dim *d, float *dst, const float *src4, const float *blur1, int pattern, int radius,
                    float sstd, float cstd, float dstd, float dpow, float gspeed)
 {
     float spa[32];
@@ -137,16 +158,16 @@ void ref_bilateral(const ref_dim *d, float *dst, const float *src4, const float 
 /* cuburn/filters.py:62-95 Bilateral.apply: 8 directions of (den_blur -> den_blur_1c ->
  * bilateral r=15), flipping front/back after each.  `front` holds the result on return;
  * `back` (float4) and `side` (>= nbins floats) are scratch. */
-void ref_bilateral_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
+static void ref_bilateral_chain_impl(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
                          float sstd, float cstd, float dstd, float dpow, float gspeed)
 {
     size_t n = (size_t)d->ah * d->astride;
     float *b1 = malloc(n * sizeof(float));
     float *f = front, *b = back;
     for (int p = 0; p < 8; ++p) {
-        ref_den_blur(d, b1, f, p, 0, coefs);
-        ref_den_blur_1c(d, side, b1, p, 1, coefs);
-        ref_bilateral(d, b, f, side, p, 15, sstd, cstd, dstd, dpow, gspeed);
+        ref_den_blur_impl(d, b1, f, p, 0, coefs);
+        ref_den_blur_1c_impl(d, side, b1, p, 1, coefs);
+        ref_bilateral_impl(d, b, f, side, p, 15, sstd, cstd, dstd, dpow, gspeed);
         float *t = f; f = b; b = t;
     }
     /* 8 flips: result is in the original front */
@@ -154,7 +175,7 @@ void ref_bilateral_chain(const ref_dim *d, float *front, float *back, float *sid
 }
 
 /* cuburn/code/filters.py:41-53 */
-void ref_logscale(const ref_dim *d, float *buf, float k1, float k2)
+static void ref_logscale_impl(const ref_dim *d, float *buf, float k1, float k2)
 {
     size_t n = (size_t)d->ah * d->astride;
     for (size_t i = 0; i < n; ++i) {
@@ -165,7 +186,7 @@ void ref_logscale(const ref_dim *d, float *buf, float k1, float k2)
 }
 
 /* cuburn/code/filters.py:354-412 */
-void ref_colorclip(const ref_dim *d, float *buf, float vib, float highpow, float gam, float lin, float lingam)
+static void ref_colorclip_impl(const ref_dim *d, float *buf, float vib, float highpow, float gam, float lin, float lingam)
 {
     size_t n = (size_t)d->ah * d->astride;
     for (size_t i = 0; i < n; ++i) {
@@ -202,7 +223,7 @@ void ref_colorclip(const ref_dim *d, float *buf, float vib, float highpow, float
 }
 
 /* cuburn/code/filters.py:294-328 + cuburn/filters.py:142-163 */
-void ref_smearclip_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
+static void ref_smearclip_chain_impl(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
                          float gam_m_1, float lin, float lingam)
 {
     size_t n = (size_t)d->ah * d->astride;
@@ -212,10 +233,10 @@ void ref_smearclip_chain(const ref_dim *d, float *front, float *back, float *sid
         if (p[3] > 0.0f) ls = fmaxf(0.0f, p[3] - 1.0f) / p[3];
         for (int k = 0; k < 4; ++k) side[4 * i + k] = p[k] * ls;
     }
-    ref_full_blur(d, back, side, 2, 0, coefs);
-    ref_full_blur(d, side, back, 3, 0, coefs);
-    ref_full_blur(d, back, side, 0, 0, coefs);
-    ref_full_blur(d, side, back, 1, 0, coefs);
+    ref_full_blur_impl(d, back, side, 2, 0, coefs);
+    ref_full_blur_impl(d, side, back, 3, 0, coefs);
+    ref_full_blur_impl(d, back, side, 0, 0, coefs);
+    ref_full_blur_impl(d, side, back, 1, 0, coefs);
     for (size_t i = 0; i < n; ++i) {       /* smearclip: front += side, gamma */
         float *p = &front[4 * i];
         for (int k = 0; k < 4; ++k) p[k] += side[4 * i + k];
@@ -230,12 +251,12 @@ void ref_smearclip_chain(const ref_dim *d, float *front, float *back, float *sid
 }
 
 /* cuburn/code/filters.py:268-288 + cuburn/filters.py:113-130; side/back used as 1-channel scratch */
-void ref_haloclip_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs, float gam_m_1)
+static void ref_haloclip_chain_impl(const ref_dim *d, float *front, float *back, float *side, const float *coefs, float gam_m_1)
 {
     size_t n = (size_t)d->ah * d->astride;
     for (size_t i = 0; i < n; ++i) side[i] = powf(front[4 * i], 0.1f);   /* apply_gamma reads pix.x (:270-271) */
-    ref_den_blur_1c(d, back, side, 2, 0, coefs);
-    ref_den_blur_1c(d, side, back, 3, 0, coefs);
+    ref_den_blur_1c_impl(d, back, side, 2, 0, coefs);
+    ref_den_blur_1c_impl(d, side, back, 3, 0, coefs);
     for (size_t i = 0; i < n; ++i) {
         float *p = &front[4 * i];
         if (p[3] <= 0) { p[0] = p[1] = p[2] = p[3] = 0.0f; continue; }
@@ -245,7 +266,7 @@ void ref_haloclip_chain(const ref_dim *d, float *front, float *back, float *side
 }
 
 /* cuburn/code/filters.py:332-350 */
-void ref_plainclip(const ref_dim *d, float *buf, float gam_m_1, float lin, float lingam, float brightness)
+static void ref_plainclip_impl(const ref_dim *d, float *buf, float gam_m_1, float lin, float lingam, float brightness)
 {
     size_t n = (size_t)d->ah * d->astride;
     for (size_t i = 0; i < n; ++i) {
@@ -261,7 +282,7 @@ void ref_plainclip(const ref_dim *d, float *buf, float gam_m_1, float lin, float
 }
 
 /* cuburn/code/filters.py:81-90 */
-void ref_logencode(const ref_dim *d, float *dst, const float *src, float degamma)
+static void ref_logencode_impl(const ref_dim *d, float *dst, const float *src, float degamma)
 {
     size_t n = (size_t)d->ah * d->astride * 4;
     for (size_t i = 0; i < n; ++i) dst[i] = log2f(powf(src[i], degamma)) / 12.0f + 1.0f;
@@ -278,7 +299,7 @@ static inline float dclampf(ref_mwc *r, float peak, float in)
 /* cuburn/code/output.py:20-71 f32_to_rgba_u8 / _u16: gutter crop (isrc = sstride*(y+g)+x+g),
  * dithered quantise, truncating convert.  RNG assignment of the device model: state t serves
  * pixels t, t+nrng, t+2*nrng, ... (row-major over the w x h output) in that order. */
-void ref_f32_to_rgba(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst)
+static void ref_f32_to_rgba_impl(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst)
 {
     size_t npix = (size_t)d->w * d->h;
     float peak = fmt ? 65535.0f : 255.0f;
@@ -292,4 +313,85 @@ void ref_f32_to_rgba(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t 
                 else ((uint8_t *)dst)[4 * p + k] = (uint8_t)v;
             }
         }
+}
+
+/* ---- public entry points: flush-to-zero wrappers (see fz_enter) ---- */
+void ref_yuv_to_rgb(const ref_dim *d, float *dst, const float *src)
+{
+    fz_state s = fz_enter();
+    ref_yuv_to_rgb_impl(d, dst, src);
+    fz_leave(s);
+}
+void ref_den_blur(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
+{
+    fz_state s = fz_enter();
+    ref_den_blur_impl(d, dst, src4, pattern, upsample, coefs);
+    fz_leave(s);
+}
+void ref_den_blur_1c(const ref_dim *d, float *dst, const float *src1, int pattern, int upsample, const float *coefs)
+{
+    fz_state s = fz_enter();
+    ref_den_blur_1c_impl(d, dst, src1, pattern, upsample, coefs);
+    fz_leave(s);
+}
+void ref_full_blur(const ref_dim *d, float *dst, const float *src4, int pattern, int upsample, const float *coefs)
+{
+    fz_state s = fz_enter();
+    ref_full_blur_impl(d, dst, src4, pattern, upsample, coefs);
+    fz_leave(s);
+}
+void ref_bilateral(const ref_dim *d, float *dst, const float *src4, const float *blur1, int pattern, int radius,
+                   float sstd, float cstd, float dstd, float dpow, float gspeed)
+{
+    fz_state s = fz_enter();
+    ref_bilateral_impl(d, dst, src4, blur1, pattern, radius, sstd, cstd, dstd, dpow, gspeed);
+    fz_leave(s);
+}
+void ref_bilateral_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
+                         float sstd, float cstd, float dstd, float dpow, float gspeed)
+{
+    fz_state s = fz_enter();
+    ref_bilateral_chain_impl(d, front, back, side, coefs, sstd, cstd, dstd, dpow, gspeed);
+    fz_leave(s);
+}
+void ref_logscale(const ref_dim *d, float *buf, float k1, float k2)
+{
+    fz_state s = fz_enter();
+    ref_logscale_impl(d, buf, k1, k2);
+    fz_leave(s);
+}
+void ref_colorclip(const ref_dim *d, float *buf, float vib, float highpow, float gam, float lin, float lingam)
+{
+    fz_state s = fz_enter();
+    ref_colorclip_impl(d, buf, vib, highpow, gam, lin, lingam);
+    fz_leave(s);
+}
+void ref_smearclip_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs,
+                         float gam_m_1, float lin, float lingam)
+{
+    fz_state s = fz_enter();
+    ref_smearclip_chain_impl(d, front, back, side, coefs, gam_m_1, lin, lingam);
+    fz_leave(s);
+}
+void ref_haloclip_chain(const ref_dim *d, float *front, float *back, float *side, const float *coefs, float gam_m_1)
+{
+    fz_state s = fz_enter();
+    ref_haloclip_chain_impl(d, front, back, side, coefs, gam_m_1);
+    fz_leave(s);
+}
+void ref_plainclip(const ref_dim *d, float *buf, float gam_m_1, float lin, float lingam, float brightness)
+{
+    fz_state s = fz_enter();
+    ref_plainclip_impl(d, buf, gam_m_1, lin, lingam, brightness);
+    fz_leave(s);
+}
+void ref_logencode(const ref_dim *d, float *dst, const float *src, float degamma)
+{
+    fz_state s = fz_enter();
+    ref_logencode_impl(d, dst, src, degamma);
+    fz_leave(s);
+}
+void ref_f32_to_rgba(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst)
+{
+    ref_f32_to_rgba_impl(d, src, rng, nrng, fmt, dst);      /* integer output: no denormal-sensitive step */
 }
