@@ -71,6 +71,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (0 = skip)')
+    ap.add_argument('--preheat-seconds', type=float, default=3.0,
+                    help='untimed frames rendered before the W warm-up steps so that the GPU has left its idle '
+                         'power state (a fresh box needs seconds of load before sclk ramps up; the iterate kernel '
+                         'is latency/ALU-bound and runs ~1.6x slower until then)')
     ap.add_argument('--shard', default='frames', choices=['frames', 'samples'],
                     help="multi-GPU split: whole frames per rank (default, weak scaling, the reference's "
                          "distribute.py model) or the samples of each single frame with one RCCL "
@@ -131,6 +135,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_heat = time.perf_counter()
+    while time.perf_counter() - t_heat < args.preheat_seconds:
+        run(4)
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
@@ -196,7 +203,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
                        'samples_per_frame': mgr.last_nsamples, 'stream_lanes': 2,
-                       'accum': args.accum, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
+                       'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
                        'parallelism': ('frame-sharded x%d, RCCL gather' if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators') % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
