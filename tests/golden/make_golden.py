@@ -60,6 +60,109 @@ def prepare_reference():
     return tmp, dst
 
 
+def genome_xml_cases():
+    """flam3 XML inputs for the conversion fixtures (the first is the reference's own test flame,
+    genome/tests/test_convert.py:20-36)."""
+    return {
+        'ref_test': """
+<flame time="0" size="1280 960" center="0.01 0.02" scale="40" oversample="2"
+    filter="1" quality="500" batches="50" brightness="4" gamma="4"
+    url="test.com" nick="strobe" >
+    <color index="0" rgb="1 2 3"/>
+    <xform weight="0.1" color="0" hyperbolic="0.1"
+        coefs="01 0.2 -0.3 0.4 -0.5 0.6"/>
+</flame>""",
+        'rich': """
+<flames name="pack">
+<flame name="rich" size="640 480" center="-0.25 0.5" scale="120" rotate="30" filter="0.8"
+    brightness="3.5" gamma="3" gamma_threshold="0.02" highlight_power="1.5" vibrancy="0.9"
+    estimator_radius="9" estimator_minimum="0.5" estimator_curve="0.4">
+    <xform weight="0.5" color="0.25 0.1" symmetry="0.5" linear="0.6" spherical="0.4"
+        coefs="0.7 0.1 -0.2 0.9 0.3 -0.4" post="1.1 0 0 0.9 0.05 0" chaos="1 0.5 2"/>
+    <xform weight="0.25" color="0.75" color_speed="0.3" opacity="0.5" animate="1"
+        julian="1" julian_power="3" julian_dist="0.8" curl="0.2" curl_c1="0.1" curl_c2="-0.3"
+        coefs="-0.5 0.5 0.5 0.5 0 0"/>
+    <xform weight="0.25" color="1" symmetry="1" blob="1" blob_low="0.2" blob_high="1.2" blob_waves="5"
+        coefs="1 0 0 1 0 0" post="1 0 0 1 0 0"/>
+    <finalxform color="0" symmetry="1" linear="1" coefs="1.2 0 0 1.2 0.1 0.1"/>
+    <color index="3" rgb="255 128 0"/>
+    <color index="255" rgb="10 20 30"/>
+</flame>
+<flame name="symm" size="100 100" scale="25" brightness="4" gamma="4">
+    <symmetry kind="-3"/>
+    <xform weight="1" color="0" swirl="1" coefs="0.5 0 0 0.5 0.5 0"/>
+</flame>
+</flames>""",
+    }
+
+
+def genome_db_case(nodes):
+    """A one-file genome database: converted nodes, hand-written nodes (velocities, wide spreads,
+    hole / identity variations, final xforms, a base chain) and edges with edits."""
+    A = {'type': 'node', 'name': 'A',
+         'camera': {'scale': 0.4, 'rotation': [10, 45], 'center': {'x': 0.1, 'y': -0.2}},
+         'filters': {'logscale': {'brightness': 5}},
+         'time': {'frame_width': 1.5},
+         'palette': ['rgb8', 'AAAA' * 256],
+         'xforms': {
+             '0': {'weight': 0.5, 'color': 0.1, 'pre_affine': {'angle': [30, -360], 'spread': 40, 'magnitude': {'x': 0.7, 'y': 0.6}},
+                   'variations': {'linear': {'weight': 1}}},
+             '1': {'weight': 0.3, 'color': 0.9, 'color_speed': 0.25, 'pre_affine': {'angle': 200, 'spread': 120, 'offset': {'x': 0.3, 'y': 0.1}},
+                   'post_affine': {'angle': 50, 'spread': 100},
+                   'variations': {'spherical': {'weight': 0.8}, 'linear': {'weight': 0.2}}},
+             '2': {'weight': 0.2, 'color': 0.5, 'pre_affine': {'angle': [90, 180], 'spread': 45},
+                   'variations': {'blob': {'weight': 1, 'low': 0.3, 'high': 1.1, 'waves': 4}, 'fan2': {'weight': 0.5, 'x': 0.2, 'y': 0.4}}},
+         }}
+    B = {'type': 'node', 'name': 'B',
+         'camera': {'scale': 0.5, 'rotation': [350, -90]},
+         'filters': {'colorclip': {'gamma': 3.5}},
+         'blend': {'xform_sort': 'weight'},
+         'palette': ['rgb8', '////' * 256],
+         'xforms': {
+             '0': {'weight': 0.6, 'color': 0.0, 'pre_affine': {'angle': [75, 360], 'spread': 45},
+                   'variations': {'swirl': {'weight': 1}}},
+             '1': {'weight': 0.4, 'color': 1.0, 'pre_affine': {'angle': 10, 'spread': 130},
+                   'post_affine': {'angle': 20, 'spread': 95},
+                   'variations': {'julian': {'weight': 1, 'power': 3, 'dist': 0.9}}},
+         },
+         'final_xform': {'color': 0.3, 'color_speed': 0.1, 'pre_affine': {'angle': 45, 'spread': 45, 'magnitude': {'x': 1.1, 'y': 1.1}},
+                         'variations': {'linear': {'weight': 1}}}}
+    C = {'type': 'node', 'name': 'C', 'base': 'A',
+         'camera': {'scale': 0.8},
+         'xforms': {'3': {'weight': 0.1, 'color': 0.2, 'variations': {'perspective': {'weight': 1, 'angle': 0.4, 'dist': 2}}}}}
+    edge1 = {'type': 'edge', 'link': {'src': 'A@0.25', 'dst': 'B@0'},
+             'blend': {'duration': 3, 'xform_sort': 'weightflip'},
+             'camera': {'scale': [0.5, 0.45]},
+             'xforms': {'src': {'0': {'weight': [0.5, 0.7]}}, 'dst': {'1': {'color': [0.25, 0.6], 'weight': [0, 0.1, 1, 0.5]}}}}
+    edge2 = {'type': 'edge', 'link': {'src': 'B@0.5', 'dst': 'C@-0.25'},
+             'blend': {'duration': 2, 'xform_sort': 'natural', 'xform_map': [['0', '2'], ['1', 'dup'], ['pad', '0']]},
+             'final_xform': {'color': [0.5, 0.9]}}
+    edge3 = {'type': 'edge', 'base': 'edge1', 'link': {'src': 'A@0.25', 'dst': 'B@0'},
+             'blend': {'xform_sort': 'color'},
+             'xforms': {'src': {'0': {'weight': [0.25, 0.1]}}}}
+    out = {'type': 'onefiledb', 'A': A, 'B': B, 'C': C, 'edge1': edge1, 'edge2': edge2, 'edge3': edge3}
+    out['X_ref_test'] = nodes['ref_test'][0]
+    rich = json.loads(json.dumps(nodes['rich'][0]))
+    for xf in rich['xforms'].values():
+        xf.pop('chaos', None)        # converted but not in the node schema: resolve() raises KeyError on it
+    out['X_rich'] = rich
+    out['X_symm'] = nodes['rich'][1]
+    return out
+
+
+def jsonable(obj):
+    """bytes -> str (py3 base64), numpy scalars -> python, integer dict keys -> str (what json does)."""
+    if isinstance(obj, dict):
+        return dict((str(k), jsonable(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return [jsonable(v) for v in obj]
+    if isinstance(obj, bytes):
+        return obj.decode('ascii')
+    if isinstance(obj, np.generic):
+        return obj.item()
+    return obj
+
+
 def dump(name, obj):
     with open(os.path.join(HERE, name), 'w') as fp:
         json.dump(obj, fp, indent=1, sort_keys=True)
@@ -213,6 +316,47 @@ def main():
     enc = base64.b64encode(pal.tobytes()).decode()
     dec = palette_decode(['rgb8'] + [enc[i:i + 64] for i in range(0, len(enc), 64)])
     dump('palette.json', {'b64': enc, 'decoded_head': dec[:4].tolist(), 'decoded_sum': float(dec.sum())})
+
+    # ---- 10. Genome front-end: flam3 XML -> node (genome/convert.py), node/edge -> animation
+    #          (genome/blend.py), house-style JSON text (genome/util.py:99-144).  The reference is
+    #          py2: its round() (halves away from zero) is put back into the converted module.
+    import math
+    from cuburn.genome import convert as ref_convert, blend as ref_blend, db as ref_db
+    from cuburn.genome import util as ref_gutil
+    ref_blend.round = lambda x: math.copysign(math.floor(abs(x) + 0.5), x)
+    ref_gutil.basestring = str
+    front = {'xml': {}, 'nodes': {}, 'anims': {}, 'json_text': {}}
+    for name, xml in genome_xml_cases().items():
+        flames = ref_convert.XMLGenomeParser.parse(xml)
+        front['xml'][name] = xml
+        front['nodes'][name] = [jsonable(ref_convert.flam3_to_node(f)) for f in flames]
+    dbdoc = genome_db_case(front['nodes'])
+    front['db'] = dbdoc
+    gdb = ref_db.OneFileDB(json.loads(json.dumps(dbdoc)))
+    for key, doc in sorted(dbdoc.items()):
+        if not isinstance(doc, dict):
+            continue
+        if doc['type'] == 'node':
+            for half in (False, True):
+                a = ref_blend.node_to_anim(gdb, json.loads(json.dumps(doc)), half)
+                front['anims']['%s/%s' % (key, 'half' if half else 'full')] = a
+        elif doc['type'] == 'edge':
+            front['anims'][key] = ref_blend.edge_to_anim(gdb, json.loads(json.dumps(doc)))
+    for k, a in front['anims'].items():
+        front['json_text'][k] = ref_gutil.json_encode(json.loads(json.dumps(a)))
+    front['tospline'] = []
+    from cuburn.genome import spectypes as ref_st
+    for spl_args in (dict(), dict(period=360), dict(var=True), dict(default=45, period=360)):
+        spl = ref_st.spline(spl_args.get('default', 0), period=spl_args.get('period'))._replace(var=spl_args.get('var', False))
+        for src_v, dst_v, edit, dur in [
+                (None, None, None, 1), (1, 1, None, 1), (1, 2, None, 1), (None, 3, None, 2),
+                ([10, 180], [20, 180], None, 1), ([10, 180], [20, 180], None, 2), ([10, -360], [10, -360], None, 1),
+                ([350, 90], [5, 0], None, 1), ([0, 720], [90, 0], None, 0.5), (30, [60, -45], None, 3),
+                (1, 2, [0, 5, 1, 7], 1), (1, 2, [0.5, 9], 1), ([0, 360], [0, 360], [0, 725, 1, -10, 0.25, 3], 1),
+                (0.5, 0.5, [0.3, None], 1)]:
+            front['tospline'].append({'spl': spl_args, 'src': src_v, 'dst': dst_v, 'edit': edit, 'duration': dur,
+                                      'out': ref_blend.tospline(spl, src_v, dst_v, edit, dur)})
+    dump('genome_front.json', front)
 
     shutil.rmtree(tmp)
 

@@ -7,6 +7,7 @@ float parameter preparation and every filter.  Distributional: histograms of fla
 variations use hardware transcendentals.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -592,3 +593,28 @@ def test_sample_sharded_frame_two_virtual_ranks(built):
     assert abs(a.mean() - whole[0].mean()) < 1.0
     for m in mgrs:
         m.fb.free()
+
+
+def test_flam3_xml_to_frame(mgr, tmp_path):
+    """Front end to pixels: flam3 XML -> node -> looping animation (genome.db.get_anim) -> queue_frame."""
+    import json
+    from cuburn_amd.genome import db
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
+    src = gold['xml']['rich'].replace(' chaos="1 0.5 2"', '')
+    path = tmp_path / 'rich.flam3'
+    path.write_text(src)
+    with pytest.warns(UserWarning):
+        gnm, base = db.connect(str(tmp_path)).get_anim(str(path))      # two flames in the file: first is used
+    assert base == 'rich' and gnm['type'] == 'animation'
+    prof = dict(configs.cfg2()[1], width=320, height=240)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    frames = []
+    for tc in (0.1, 0.6):
+        evt, h = mgr.queue_frame(rdr, gnm, gprof, tc)
+        evt.synchronize()
+        frames.append(np.array(h))
+    for f in frames:
+        assert f.shape == (240, 320, 4) and np.isfinite(f.astype(np.float32)).all()
+        assert (f[..., 3] > 0).mean() > 0.05 and f[..., :3].max() > 60
+    assert np.abs(frames[0].astype(np.int32) - frames[1].astype(np.int32)).mean() > 0.5     # the loop moves
