@@ -120,3 +120,81 @@ def test_unknown_variation_rejected_on_host():
         GenomePacker({'type': 'animation', 'xforms': {'0': {'variations': {'nonesuch': {'weight': 1}}}}})
     with pytest.raises(ValueError):
         GenomePacker({'type': 'animation', 'xforms': {}})
+
+
+def _wrap_output(otype, **kw):
+    gnm, prof = configs.cfg1()
+    return profile.wrap(dict(prof, output=dict(type=otype, **kw)), gnm)
+
+
+def test_output_modules_for_profile_types():
+    """Module / suffix selection follows cuburn/output.py:411-436."""
+    assert output.get_suffix_for_profile(_wrap_output('jpeg')) == '.jpg'
+    assert output.get_suffix_for_profile(_wrap_output('jpeg', alpha=True)) == '_color.jpg'
+    assert output.get_suffix_for_profile(_wrap_output('png')) == '.png'
+    assert output.get_suffix_for_profile(_wrap_output('tiff')) == '.tiff'
+    o = output.get_output_for_profile(_wrap_output('tiff'))
+    assert isinstance(o, output.TiffOutput) and o.fmt == 1 and o.dtype == 'u2'
+    o = output.get_output_for_profile(_wrap_output('jpeg', quality=90))
+    assert isinstance(o, output.PILOutput) and o.fmt == 0 and o.quality == 90
+    for video in ('x264', 'vp8', 'vp9', 'prores'):
+        with pytest.raises(ValueError):
+            output.get_output_for_profile(_wrap_output(video))
+    with pytest.raises(ValueError):
+        output.get_output_for_profile(_wrap_output('bogus'))
+
+
+def test_jpeg_png_tiff_encode_decode():
+    PIL = pytest.importorskip('PIL.Image')
+    rs = np.random.RandomState(1)
+    yy, xx = np.mgrid[0:24, 0:32]
+    img = np.stack([xx * 8, yy * 10, (xx + yy) * 4, 255 - xx * 7], -1).astype(np.uint8)
+    media, logs = output.PILOutput('png', alpha=True).encode(img)
+    assert list(media) == ['.png'] and np.array_equal(np.array(PIL.open(media['.png'])), img)
+    media, _ = output.PILOutput('jpeg', quality=100).encode(img)
+    dec = np.array(PIL.open(media['.jpg'])).astype(int)
+    assert dec.shape == (24, 32, 3) and np.abs(dec - img[..., :3]).mean() < 3
+    media, _ = output.PILOutput('jpeg', alpha=True).encode(img)
+    assert sorted(media) == ['_alpha.jpg', '_color.jpg']
+    assert np.abs(np.array(PIL.open(media['_alpha.jpg'])).astype(int) - img[..., 3]).mean() < 3
+    # the built-in PNG writer decodes to the same pixels
+    media, _ = output.PNGOutput().encode(img)
+    assert np.array_equal(np.array(PIL.open(media['.png'])), img[..., :3])
+    # 8-bit TIFF through Pillow; 16-bit RGB(A) is beyond Pillow: parse the baseline tags by hand
+    t8 = output._tiff_bytes(img[..., :3])
+    assert np.array_equal(np.array(PIL.open(__import__('io').BytesIO(t8))), img[..., :3])
+    img16 = rs.randint(0, 65536, (6, 5, 4)).astype(np.uint16)
+    for alpha in (False, True):
+        media, _ = output.TiffOutput(alpha=alpha).encode(img16)
+        data = media['.tiff'].read()
+        want = img16 if alpha else img16[..., :3]
+        assert data[:4] == b'II*\x00'
+        ifd = int.from_bytes(data[4:8], 'little')
+        n = int.from_bytes(data[ifd:ifd + 2], 'little')
+        tags = {}
+        for i in range(n):
+            e = data[ifd + 2 + 12 * i: ifd + 14 + 12 * i]
+            tag, typ, cnt = int.from_bytes(e[0:2], 'little'), int.from_bytes(e[2:4], 'little'), int.from_bytes(e[4:8], 'little')
+            size = {3: 2, 4: 4}[typ] * cnt
+            raw = e[8:8 + size] if size <= 4 else data[int.from_bytes(e[8:12], 'little'):][:size]
+            tags[tag] = np.frombuffer(raw, '<u2' if typ == 3 else '<u4').tolist()
+        assert list(tags) == sorted(tags)                       # IFD entries ascending, as TIFF requires
+        assert tags[256] == [5] and tags[257] == [6] and tags[258] == [16] * want.shape[2]
+        assert tags[259] == [1] and tags[262] == [2] and tags[277] == [want.shape[2]]
+        assert (338 in tags) == alpha
+        pix = np.frombuffer(data[tags[273][0]: tags[273][0] + tags[279][0]], '<u2').reshape(want.shape)
+        assert np.array_equal(pix, want)
+    assert output.TiffOutput().encode(None) == ({}, [])
+
+
+def test_cli_print_blended_animation(tmp_path, capsys):
+    """python -m cuburn_amd ID --print: genome db lookup + node -> animation, no GPU involved."""
+    import json
+    from cuburn_amd import __main__ as cli
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
+    (tmp_path / 'A.json').write_text(json.dumps(gold['db']['A']))
+    assert cli.main(['A', '-d', str(tmp_path), '--print']) == 0
+    text = capsys.readouterr().out
+    assert text == gold['json_text']['A/full'] + '\n'
+    assert cli.main(['A', '-d', str(tmp_path), '--print', '--half']) == 0
+    assert capsys.readouterr().out == gold['json_text']['A/half'] + '\n'

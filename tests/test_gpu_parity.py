@@ -618,3 +618,27 @@ def test_flam3_xml_to_frame(mgr, tmp_path):
         assert f.shape == (240, 320, 4) and np.isfinite(f.astype(np.float32)).all()
         assert (f[..., 3] > 0).mean() > 0.05 and f[..., :3].max() > 60
     assert np.abs(frames[0].astype(np.int32) - frames[1].astype(np.int32)).mean() > 0.5     # the loop moves
+
+
+@pytest.mark.parametrize('codec,suffix', [('png', '.png'), ('tiff', '.tiff'), ('jpeg', '.jpg')])
+def test_cli_renders_still(built, tmp_path, codec, suffix):
+    """python -m cuburn_amd FLAME --still --codec ...: the reference's main.py flow end to end."""
+    import json, subprocess, sys
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
+    (tmp_path / 'B.json').write_text(json.dumps(gold['db']['B']))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'cuburn_amd', 'B', '-d', str(tmp_path), '--still', '-P', 'preview',
+                          '--codec', codec, '-o', str(tmp_path), '--width', '320', '--height', '180', '--spp', '200'],
+                         cwd=repo, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(suffix))
+    assert len(files) == 1, (os.listdir(str(tmp_path)), out.stderr[-500:])
+    data = open(os.path.join(str(tmp_path), files[0]), 'rb').read()
+    assert len(data) > 2000
+    if codec != 'tiff':
+        PIL = pytest.importorskip('PIL.Image')
+        img = np.array(PIL.open(os.path.join(str(tmp_path), files[0])))
+        assert img.shape[:2] == (180, 320) and img.max() > 60
+    else:
+        assert data[:4] == b'II*\x00'
+    assert 'ms' in out.stderr
