@@ -8,6 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_lib', 'libflame_hip.so')
+# A/B measurements: an alternative build of the same library (never a different implementation)
+LIB_PATH = os.environ.get('FLAME_HIP_LIB', LIB_PATH)
 
 (FL_OK, FL_E_INVAL, FL_E_NOMEM, FL_E_HIP, FL_E_NODEV, FL_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5)
 

@@ -157,10 +157,10 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     const float *__restrict__ xf_final = P + xf_off + nxf * xf_stride;
 
     uint32_t phase = round0 % 3u;
-    // cumulative xform densities of this slot's temporal sample: constant for the whole launch
-    float cdf[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) cdf[i] = (i < nxf - 1) ? P[cdf_off + i] : 2.0f;
+    // Cumulative xform densities of this slot's temporal sample (constant for the launch), one
+    // per lane: the wave-uniform choice is then ONE vector compare + find-first-set instead
+    // of a scalar compare chain.  Lanes past the last density hold 2.0 (never chosen first).
+    const float cdf_lane = ((int)l < nxf - 1 && l < 63u) ? P[cdf_off + (int)l] : 2.0f;
     const float fa_stride = (float)astride - 0.5f, fa_height = (float)aheight - 0.5f;
     const uint32_t dst0 = shuffle_dest<NW>(w, l, 0), dst1 = shuffle_dest<NW>(w, l, 1), dst2 = shuffle_dest<NW>(w, l, 2);
     uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
@@ -171,17 +171,9 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     // fetched a whole round before it is needed.
     auto choose = [&](uint32_t sel) -> int {
         const float xfsel = (float)sel * (1.0f / 4294967296.0f);
-        int k;
-        if (nxf <= 8) {
-            k = 7;
-#pragma unroll
-            for (int i = 6; i >= 0; --i) if (xfsel <= cdf[i]) k = i;
-            k = min(k, nxf - 1);
-        } else {
-            k = nxf - 1;
-            for (int i = nxf - 2; i >= 0; --i) if (xfsel <= P[cdf_off + i]) k = i;
-        }
-        return __builtin_amdgcn_readfirstlane(k);
+        // smallest i with xfsel <= cdf[i]; nxf - 1 if there is none (iter.py:260-272)
+        const unsigned long long le = __ballot(xfsel <= cdf_lane) | (1ull << 63);
+        return min((int)__builtin_ctzll(le), nxf - 1);
     };
     uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
     const float *__restrict__ xf_next = P + xf_off + choose(sel_next) * xf_stride;
@@ -249,7 +241,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         } else if (ACC == 1) {
             // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
             // and written to this slot's private region of the sample log (no global atomics)
-            const uint32_t bin = ok ? (iy >> FL_TILE_H_LOG2) * bg.tiles_x + (ix >> 7) : bg.nbins;
+            const uint32_t bin = ok ? __umul24(iy >> FL_TILE_H_LOG2, bg.tiles_x) + (ix >> 7) : bg.nbins;
             const uint32_t rec = (bin << FL_REC_BITS) | ((iy & (FL_TILE_H - 1u)) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
 #ifdef ABL_NOSTAGE
             if (rec == 0x12345678u) stage[tid] = rec;
