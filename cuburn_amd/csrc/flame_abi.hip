@@ -177,7 +177,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->nslots = nslots;
     const char *env_nw = getenv("FLAME_NW");
     if (env_nw && atoi(env_nw) == 8) c->nw = 8;
-    if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_rounds = (uint32_t)v; }
+    if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
     c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256 + FL_NOUT;
     if (nseeds != c->nwalkers) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*nw*64 + 64*256 + 65536", __FILE__, __LINE__); }

@@ -75,6 +75,7 @@ __device__ __forceinline__ uint32_t trunca(float f) {
 #define FL_TILE_CELLS (FL_TILE_W * FL_TILE_H)
 #define FL_REC_BITS (15u + FL_TILE_H_LOG2)   /* ly + lx 7 + ci 8 */
 #define FL_MAX_BINS 2047u
+#define FL_BIN_R_MAX 16          /* rounds per sorted batch (records a thread holds in registers) */
 
 // XCD id of the executing workgroup (HW_REG_XCC_ID, bits [3:0])
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7; }

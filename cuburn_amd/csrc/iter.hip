@@ -129,8 +129,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     float (*swp)[3][NT] = reinterpret_cast<float (*)[3][NT]>(smem);                    // [2][3][NT]
     u64 *palrow = reinterpret_cast<u64 *>(smem + 2 * 3 * NT * 4);                      // [256]   (ACC != 1)
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (ACC == 1)
-    uint32_t *sorted = stage + bg.rounds * NT;                                         // [R*NT]
-    uint32_t *cnt = sorted + bg.rounds * NT;                                           // [B+1]
+    uint32_t *cnt = stage + bg.rounds * NT;                                            // [B+1]
     uint32_t *cur = cnt + ((bg.nbins + 1 + 3) & ~3u);                                  // [B+1]
     uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
 
@@ -193,13 +192,9 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
             const uint32_t par = rd & 1u, dst = phase == 0 ? dst0 : (phase == 1 ? dst1 : dst2);
-#ifndef ABL_NOSWAP
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
-#else
-            (void)par; (void)dst;
-#endif
             phase = phase == 2 ? 0 : phase + 1;
         }
         if (rd < fuse) continue;                                            // iter.py:298-300
@@ -243,24 +238,18 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
             // and written to this slot's private region of the sample log (no global atomics)
             const uint32_t bin = ok ? __umul24(iy >> FL_TILE_H_LOG2, bg.tiles_x) + (ix >> 7) : bg.nbins;
             const uint32_t rec = (bin << FL_REC_BITS) | ((iy & (FL_TILE_H - 1u)) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
-#ifdef ABL_NOSTAGE
-            if (rec == 0x12345678u) stage[tid] = rec;
-            continue;
-#endif
             stage[staged * NT + tid] = rec;
-#ifndef ABL_NOCNT
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-#ifdef ABL_NOFLUSH
-            if (++staged == bg.rounds) staged = 0;
-            if (false) {
-#else
             if (++staged == bg.rounds || rd + 1 == nrounds) {
-#endif
-                const uint32_t n = staged * NT;
                 const uint32_t batch_id = batch_in_slot * gridDim.x + slot;
                 __syncthreads();
-                if (w == 0) {                       // exclusive scan of the bin counts, directory entries
+                // Each thread takes its own staged records into registers (while wave 0 scans the
+                // tile counts), so that the scatter below can sort the batch IN PLACE: no second
+                // R*NT buffer, which is what limits the workgroups per CU.
+                uint32_t r2[FL_BIN_R_MAX];
+#pragma unroll
+                for (int q = 0; q < FL_BIN_R_MAX; ++q) r2[q] = (uint32_t)q < staged ? stage[q * NT + tid] : 0xffffffffu;
+                if (w == 0) {                       // exclusive scan of the tile counts, directory entries
                     uint32_t running = 0;
                     for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
                         const uint32_t b = c0 + l;
@@ -268,11 +257,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                         const uint32_t incl = wave_incl_scan(v, l);
                         const uint32_t excl = incl - v + running;
                         if (b <= bg.nbins) { cur[b] = excl; cnt[b] = 0; }
-#ifdef ABL_DIRBM
-                        if (b < bg.nbins) bin_dir[(size_t)batch_id * bg.nbins + b] = (excl << 16) | v;
-#else
                         if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
-#endif
                         if (b == bg.nbins) *s_nvalid = excl;
                         running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     }
@@ -280,22 +265,22 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                 __syncthreads();
                 // scatter, four records per thread in flight (the returning LDS atomic is a
                 // ~100-cycle round trip; one at a time this loop was a quarter of the kernel)
-                for (uint32_t i0 = 0; i0 < n; i0 += 4 * NT) {
-                    uint32_t r2[4], pos[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * NT + tid; r2[q] = i < n ? stage[i] : 0xffffffffu; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (r2[q] != 0xffffffffu)
-                            pos[q] = __hip_atomic_fetch_add(cur + (r2[q] >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int q0 = 0; q0 < FL_BIN_R_MAX; q0 += 4) {
+                    if ((uint32_t)q0 >= staged) break;
+                    uint32_t pos[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (r2[q] != 0xffffffffu) sorted[pos[q]] = r2[q] & ((1u << FL_REC_BITS) - 1u);
+                        if (r2[q0 + q] != 0xffffffffu)
+                            pos[q] = __hip_atomic_fetch_add(cur + (r2[q0 + q] >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (r2[q0 + q] != 0xffffffffu) stage[pos[q]] = r2[q0 + q] & ((1u << FL_REC_BITS) - 1u);
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;
                 uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
-                const uint4 *src = reinterpret_cast<const uint4 *>(sorted);
+                const uint4 *src = reinterpret_cast<const uint4 *>(stage);
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
                 staged = 0; ++batch_in_slot;
                 __syncthreads();
@@ -390,7 +375,7 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
-    if (acc == 1) b += 2 * (size_t)rounds * nt * 4 + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
+    if (acc == 1) b += (size_t)rounds * nt * 4 + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
     else b += FL_PAL_W * 8;
     return b;
 }
