@@ -324,22 +324,31 @@ __device__ __forceinline__ void apply_variation(int id, float w, const float *__
                                                 const float *__restrict__ xf,
                                                 float &tx, float &ty, float &ox, float &oy, mwc_t &r)
 {
-    const float r2 = fmaf(tx, tx, ty * ty);
-    if (id == 0) { OUT(tx * VW, ty * VW); }                                             // linear
-    else if (id == 2) { float k = fdiv(VW, r2); OUT(tx * k, ty * k); }                  // spherical
-    else if (id == 3) { float s = fsin(r2), c = fcos(r2);                               // swirl
-                        OUT(VW * (s * tx - c * ty), VW * (c * tx + s * ty)); }
-    else if (id == 1) { OUT(VW * fsin(tx), VW * fsin(ty)); }                            // sinusoidal
-    else if (id == 4) { float k = fdiv(VW, fsqrt(r2));                                  // horseshoe
-                        OUT(k * (tx - ty) * (tx + ty), 2.0f * tx * ty * k); }
-    else if (id == 27) { float k = fdiv(2.0f * VW, fsqrt(r2) + 1.0f); OUT(k * tx, k * ty); }   // eyefish
-    else if (id == 28) { float k = fdiv(VW, 0.25f * r2 + 1.0f); OUT(k * tx, k * ty); }  // bubble
-    else if (id == 14) { float nx = tx < 0.0f ? 2.0f : 1.0f, ny = ty < 0.0f ? 0.5f : 1.0f;   // bent
-                         OUT(VW * nx * tx, VW * ny * ty); }
-    else {
+    // Variations with an inline fast path; everything else goes through one out-of-line call.
+    // The fast set is tested first (one scalar bit test), so the switch below has no default
+    // edge: with one, the scalar control flow gets structurised into a chain of flag registers
+    // that costs more than the simple variations themselves.
+    constexpr uint32_t kFast = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 14) | (1u << 27) | (1u << 28);
+    if ((uint32_t)id >= 32u || !((kFast >> id) & 1u)) {
         VarIO io = {tx, ty, ox, oy, r.state, r.carry};
         io = apply_variation_slow(id, w, v, xf, io, r.mul);
         tx = io.tx; ty = io.ty; ox = io.ox; oy = io.oy; r.state = io.state; r.carry = io.carry;
+        return;
+    }
+    const float r2 = fmaf(tx, tx, ty * ty);
+    switch (id) {
+    case 0: { OUT(tx * VW, ty * VW); } break;                                              // linear
+    case 2: { float k = fdiv(VW, r2); OUT(tx * k, ty * k); } break;                        // spherical
+    case 3: { float s = fsin(r2), c = fcos(r2);                                            // swirl
+              OUT(VW * (s * tx - c * ty), VW * (c * tx + s * ty)); } break;
+    case 1: { OUT(VW * fsin(tx), VW * fsin(ty)); } break;                                  // sinusoidal
+    case 4: { float k = fdiv(VW, fsqrt(r2));                                               // horseshoe
+              OUT(k * (tx - ty) * (tx + ty), 2.0f * tx * ty * k); } break;
+    case 27: { float k = fdiv(2.0f * VW, fsqrt(r2) + 1.0f); OUT(k * tx, k * ty); } break;  // eyefish
+    case 28: { float k = fdiv(VW, 0.25f * r2 + 1.0f); OUT(k * tx, k * ty); } break;        // bubble
+    case 14: { float nx = tx < 0.0f ? 2.0f : 1.0f, ny = ty < 0.0f ? 0.5f : 1.0f;           // bent
+               OUT(VW * nx * tx, VW * ny * ty); } break;
+    default: __builtin_unreachable();
     }
 }
 #undef VW
