@@ -97,7 +97,7 @@ def main():
     from cuburn_amd import configs, profile, render, _lib, distributed as D
     gnm, prof = configs.CONFIGS[args.config]()
     gprof = profile.wrap(prof, gnm)
-    mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1024)), host_seed=42 + rank)
+    mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1536)), host_seed=42 + rank)
     mgr.accum_mode = _lib.ACCUM_BINNED if args.accum == 'binned' else _lib.ACCUM_ATOMIC
     if 'FLAME_FUSE' in os.environ:
         mgr.fuse = int(os.environ['FLAME_FUSE'])

@@ -62,7 +62,7 @@ struct fl_ctx {
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
     float4 *d_points = nullptr;       // [nslots*NT]
     u64 *d_counters = nullptr;
-    uint32_t bin_rounds = 12, bin_parts = 16;
+    uint32_t bin_rounds = 16, bin_parts = 16;
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};

@@ -62,7 +62,7 @@ class Framebuffers(object):
         astride = 32 * int(np.ceil(awidth / 32.))
         return Dimensions(width, height, awidth, aheight, astride)
 
-    def __init__(self, device=0, nslots=1024, host_seed=None, stream=None):
+    def __init__(self, device=0, nslots=1536, host_seed=None, stream=None):
         lib = _lib.load()
         self.nslots = nslots
         self.nw = 8 if os.environ.get('FLAME_NW') == '8' else 4       # waves per iterate workgroup
@@ -172,7 +172,7 @@ class RenderManager(object):
     # margin.  Set to 256 for the reference's literal schedule.
     fuse = 64
 
-    def __init__(self, device=None, nslots=1024, host_seed=None, stream=None):
+    def __init__(self, device=None, nslots=1536, host_seed=None, stream=None):
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', 0)) if 'LOCAL_RANK' in os.environ else 0
         self.fb = Framebuffers(device, nslots, host_seed, stream)
