@@ -155,13 +155,14 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     const float cam0 = P[0], cam1 = P[1], cam2 = P[2], cam3 = P[3], cam4 = P[4], cam5 = P[5];
     const float *__restrict__ xf_final = P + xf_off + nxf * xf_stride;
 
-    uint32_t phase = round0 % 3u;
     // Cumulative xform densities of this slot's temporal sample (constant for the launch), one
     // per lane: the wave-uniform choice is then ONE vector compare + find-first-set instead
     // of a scalar compare chain.  Lanes past the last density hold 2.0 (never chosen first).
     const float cdf_lane = ((int)l < nxf - 1 && l < 63u) ? P[cdf_off + (int)l] : 2.0f;
     const float fa_stride = (float)astride - 0.5f, fa_height = (float)aheight - 0.5f;
-    const uint32_t dst0 = shuffle_dest<NW>(w, l, 0), dst1 = shuffle_dest<NW>(w, l, 1), dst2 = shuffle_dest<NW>(w, l, 2);
+    // swap destinations of this and the next two rounds (phase = round % 3), rotated every round
+    uint32_t rot0 = shuffle_dest<NW>(w, l, round0 % 3u), rot1 = shuffle_dest<NW>(w, l, (round0 + 1u) % 3u),
+             rot2 = shuffle_dest<NW>(w, l, (round0 + 2u) % 3u);
     uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
     bool pend_ok = false; uint32_t pend_gi = 0; float pend_mult = 1.0f; u64 pend_old = 0;
 
@@ -191,11 +192,11 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
-            const uint32_t par = rd & 1u, dst = phase == 0 ? dst0 : (phase == 1 ? dst1 : dst2);
+            const uint32_t par = rd & 1u, dst = rot0;
+            rot0 = rot1; rot1 = rot2; rot2 = dst;           // the three-phase destination cycle
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
-            phase = phase == 2 ? 0 : phase + 1;
         }
         if (rd < fuse) continue;                                            // iter.py:298-300
 
@@ -207,8 +208,10 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         // Done in the float domain (both limits are even, so x.5 ties round outward at the top
         // and to 0 at the bottom): one compare chain instead of two saturating conversions.
         bool ok = cx >= -0.5f && cx < fa_stride && cy >= -0.5f && cy < fa_height;     // NaN -> false
-        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok ? cx : 0.0f);
-        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok ? cy : 0.0f);
+        // binned mode: a rejected sample only needs its tile number forced to "none" below, its
+        // coordinate bits are never looked at, so they are not masked here
+        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok || ACC == 1 ? cx : 0.0f);
+        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok || ACC == 1 ? cy : 0.0f);
         if (COUNT) n_oob += !ok;
         const uint32_t gi = ok ? iy * astride + ix : 0u;
 
