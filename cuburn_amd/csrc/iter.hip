@@ -207,7 +207,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         // iter.py:313-317: round to nearest even, reject outside [0, astride) x [0, aheight).
         // Done in the float domain (both limits are even, so x.5 ties round outward at the top
         // and to 0 at the bottom): one compare chain instead of two saturating conversions.
-        bool ok = cx >= -0.5f && cx < fa_stride && cy >= -0.5f && cy < fa_height;     // NaN -> false
+        bool ok = (cx >= -0.5f) & (cx < fa_stride) & (cy >= -0.5f) & (cy < fa_height);     // NaN -> false; '&': no short-circuit branches
         // binned mode: a rejected sample only needs its tile number forced to "none" below, its
         // coordinate bits are never looked at, so they are not masked here
         const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok || ACC == 1 ? cx : 0.0f);
