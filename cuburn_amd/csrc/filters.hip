@@ -309,7 +309,7 @@ template <int PATTERN> __host__ __device__ __forceinline__ constexpr int de_hy()
 
 template <int PATTERN>
 __global__ void __launch_bounds__(256)
-k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRout,
+k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRout, float *__restrict__ Wout,
                    const float4 *__restrict__ N, const float2 *__restrict__ PR,
                    float sstd, float cstd, float dstd, float dpow, float gspeed)
 {
@@ -409,17 +409,20 @@ k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRo
         const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox);
         Nout[go] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
         PRout[go].x = fpow(wn, dpow);
+        Wout[go] = wn;              // density plane: input of the next direction's blurs
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, const float4 *__restrict__ src, float dpow)
+k_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float *__restrict__ W,
+           const float4 *__restrict__ src, float dpow)
 {
     PIX_IDX(d);
     const float4 p = src[gi];
     const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
     PR[gi].x = fpow(p.w, dpow);
+    W[gi] = p.w;
 }
 
 // second density blur writing 1/(avg + 1e-6) into the .y lane of the packed plane
@@ -432,6 +435,69 @@ k_den_blur_1c_rcp2(fl_dim d, float2 *__restrict__ PR, const float *__restrict__ 
     for (int i = 0; i < 7; ++i)
         den += src[shear_idx(d, pat, xi, yi, (float)((i - 3) * (1 << upsample)))] * k.c[i];
     PR[gi].y = frcp(den + 1.0e-6f);
+}
+
+// Both density blurs of one direction in one pass (cuburn/code/filters.py:106-131 as driven by
+// cuburn/filters.py:80-84: 7 taps at step 1, then 7 taps at step 2 on the result), writing
+// 1/(avg + 1e-6) into PR.y.  A workgroup stages the density tile plus both halos in LDS
+// (edge-clamped), evaluates the first blur for the tile + second-blur halo, then the second.
+// A first-blur value at a position outside the image is, by the clamped addressing of the
+// two-kernel form, the first blur AT the clamped position; the summation order of each blur is
+// that of k_den_blur / k_den_blur_1c, so the result is bit-identical to running them in turn.
+#define DB_TW 64
+#define DB_TH 16
+template <int PATTERN, int STEP> __host__ __device__ __forceinline__ constexpr int db_hx() {
+    int m = 0;
+    for (int i = -3; i <= 3; ++i) { int v = tap_dx<PATTERN>(i * STEP); v = v < 0 ? -v : v; m = v > m ? v : m; }
+    return m;
+}
+template <int PATTERN, int STEP> __host__ __device__ __forceinline__ constexpr int db_hy() {
+    int m = 0;
+    for (int i = -3; i <= 3; ++i) { int v = tap_dy<PATTERN>(i * STEP); v = v < 0 ? -v : v; m = v > m ? v : m; }
+    return m;
+}
+
+template <int PATTERN>
+__global__ void __launch_bounds__(256)
+k_den_blur2_lds(fl_dim d, float2 *__restrict__ PR, const float *__restrict__ W, Coefs7 k)
+{
+    constexpr int H1X = db_hx<PATTERN, 1>(), H1Y = db_hy<PATTERN, 1>();
+    constexpr int H2X = db_hx<PATTERN, 2>(), H2Y = db_hy<PATTERN, 2>();
+    constexpr int SW = DB_TW + 2 * H2X, SH = DB_TH + 2 * H2Y;          // first-blur region
+    constexpr int WW = SW + 2 * H1X, WH = SH + 2 * H1Y;                // density region
+    __shared__ float sW[WH * WW];
+    __shared__ float s1[SH * SW];
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * DB_TW, by0 = blockIdx.y * DB_TH;
+    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
+
+    for (int idx = tid; idx < WH * WW; idx += 256) {
+        const int ly = idx / WW, lx = idx - ly * WW;
+        const int gx = min(max(bx0 + lx - H2X - H1X, 0), xmax), gy = min(max(by0 + ly - H2Y - H1Y, 0), ymax);
+        sW[idx] = W[(uint32_t)(gy * (int)d.astride + gx)];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SH * SW; idx += 256) {
+        const int qy = idx / SW, qx = idx - qy * SW;
+        // local density-region coordinates of the CLAMPED position
+        const int lx = min(max(bx0 + qx - H2X, 0), xmax) - bx0 + H2X + H1X;
+        const int ly = min(max(by0 + qy - H2Y, 0), ymax) - by0 + H2Y + H1Y;
+        float den = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            den += sW[(ly + tap_dy<PATTERN>(i - 3)) * WW + lx + tap_dx<PATTERN>(i - 3)] * k.c[i];
+        s1[idx] = den;
+    }
+    __syncthreads();
+    for (int o = tid; o < DB_TW * DB_TH; o += 256) {
+        const int oy = o / DB_TW, ox = o - oy * DB_TW;
+        if (bx0 + ox > xmax) continue;
+        float den = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            den += s1[(oy + H2Y + tap_dy<PATTERN>(2 * (i - 3))) * SW + ox + H2X + tap_dx<PATTERN>(2 * (i - 3))] * k.c[i];
+        PR[(uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox)].y = frcp(den + 1.0e-6f);
+    }
 }
 
 // cuburn/code/filters.py:41-53
@@ -572,21 +638,26 @@ void launch_de_bilateral(hipStream_t st, fl_dim d, int pattern, float4 *Nout, fl
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
 }
-void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, const float4 *src, float dpow) { hipLaunchKernelGGL(k_de_prep2, GRID(d), 0, st, d, N, (float2 *)PR, src, dpow); }
+void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow) { hipLaunchKernelGGL(k_de_prep2, GRID(d), 0, st, d, N, (float2 *)PR, W, src, dpow); }
+void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *c) {
+#define DB(P) case P: hipLaunchKernelGGL(k_den_blur2_lds<P>, dim3((d.astride + DB_TW - 1) / DB_TW, d.ah / DB_TH), dim3(256), 0, st, d, (float2 *)PR, W, mk(c)); break
+    switch (pattern) { DB(0); DB(1); DB(2); DB(3); DB(4); DB(5); DB(6); DB(7); default: break; }
+#undef DB
+}
 void launch_den_blur_1c_rcp2(hipStream_t st, fl_dim d, float *PR, const float *src, int p, int up, const float *c) { hipLaunchKernelGGL(k_den_blur_1c_rcp2, GRID(d), 0, st, d, (float2 *)PR, src, p, up, mk(c)); }
 template <int P>
-static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, const float4 *N, const float2 *PR,
+static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
                               float sstd, float cstd, float dstd, float dpow, float gspeed) {
     constexpr int LW = DE_TW + 2 * de_hx<P>(), LH = DE_TH + 2 * de_hy<P>();
     const size_t lds = (size_t)LW * LH * 24 + 64 + 33 * 4 + 12;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)k_de_bilateral_lds<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_de_bilateral_lds<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, N, PR,
+    hipLaunchKernelGGL(k_de_bilateral_lds<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, Wout, N, PR,
                        sstd, cstd, dstd, dpow, gspeed);
 }
-void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, const float4 *N, const float *PR,
+void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
                              float sstd, float cstd, float dstd, float dpow, float gspeed) {
-#define DE(P) case P: launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
+#define DE(P) case P: launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
 }

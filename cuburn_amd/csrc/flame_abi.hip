@@ -525,11 +525,11 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             const size_t nb2 = (size_t)d.ah * d.astride;
             float *PRa = (float *)L(c).d_side, *PRb = PRa + 2 * nb2;
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-            launch_de_prep2(st, d, Na, PRa, L(c).d_front, p[3]);
+            // density plane W: written by the prep / bilateral passes, read by the next blur pass
+            launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
             for (int pat = 0; pat < 8; ++pat) {
-                launch_den_blur(st, d, L(c).d_blur, Na, pat, 0, k7);
-                launch_den_blur_1c_rcp2(st, d, PRa, L(c).d_blur, pat, 1, k7);
-                launch_de_bilateral_lds(st, d, pat, Nb, PRb, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
+                launch_den_blur2_lds(st, d, pat, PRa, L(c).d_blur, k7);
+                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb); std::swap(PRa, PRb);
             }
             launch_de_finish(st, d, L(c).d_front, Na);

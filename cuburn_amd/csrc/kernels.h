@@ -43,9 +43,10 @@ void launch_de_finish(hipStream_t st, fl_dim d, float4 *dst, const float4 *N);
 void launch_den_blur_1c_rcp(hipStream_t st, fl_dim d, float *dst, const float *src, int pattern, int upsample, const float *coefs7);
 void launch_de_bilateral(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *Pout, const float4 *N, const float *Pw,
                          const float *RA, float sstd, float cstd, float dstd, float dpow, float gspeed);
-void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, const float4 *src, float dpow);
+void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
+void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *coefs7);
 void launch_den_blur_1c_rcp2(hipStream_t st, fl_dim d, float *PR, const float *src, int pattern, int upsample, const float *coefs7);
-void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, const float4 *N, const float *PR,
+void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
                              float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float highpow, float gam, float lin, float lingam);
