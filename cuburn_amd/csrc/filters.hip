@@ -471,10 +471,21 @@ k_den_blur2_lds(fl_dim d, float2 *__restrict__ PR, const float *__restrict__ W, 
     const int bx0 = blockIdx.x * DB_TW, by0 = blockIdx.y * DB_TH;
     const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
 
-    for (int idx = tid; idx < WH * WW; idx += 256) {
+    // all global loads are issued before the first LDS store (a rolled loop pays one L2 round
+    // trip per iteration)
+    constexpr int NIT = (WH * WW + 255) / 256;
+    float tw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = min(it * 256 + tid, WH * WW - 1);
         const int ly = idx / WW, lx = idx - ly * WW;
         const int gx = min(max(bx0 + lx - H2X - H1X, 0), xmax), gy = min(max(by0 + ly - H2Y - H1Y, 0), ymax);
-        sW[idx] = W[(uint32_t)(gy * (int)d.astride + gx)];
+        tw[it] = W[(uint32_t)(gy * (int)d.astride + gx)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < WH * WW) sW[idx] = tw[it];
     }
     __syncthreads();
     for (int idx = tid; idx < SH * SW; idx += 256) {
