@@ -642,3 +642,84 @@ def test_cli_renders_still(built, tmp_path, codec, suffix):
     else:
         assert data[:4] == b'II*\x00'
     assert 'ms' in out.stderr
+
+
+# ---------------------------------------------------------------------------------- BASELINE full size
+def test_cfg2_full_size_iterate_and_filter_chain(built):
+    """
+    BASELINE configs[1] at its real size (1920x1080, 2^28 samples) in the production
+    configuration (default slots, binned accumulate), through size-independent properties and the
+    oracle:
+      * the histogram is additive and every sample has weight 1: the density channel holds
+        integers, their sum cannot exceed the samples run, and the in-frame fraction agrees with
+        the flam3-style CPU game run at the same 2^28 samples;
+      * 8x8-block density distribution vs the CPU game (same bars as the reduced-size test);
+      * two frames with different RNG states are equal within shot noise (no state leaks from
+        frame to frame) and differ (the RNG does advance);
+      * the full filter chain (yuv -> bilateral -> logscale -> colorclip) of the full-size
+        accumulator agrees with the oracle's chain run on the same buffer, element-wise.
+    """
+    lib = _lib.load()
+    gnm, prof = configs.cfg2()
+    gprof = profile.wrap(prof, gnm)
+    m = render.RenderManager(device=0, host_seed=42)              # production defaults
+    rdr = render.Renderer(gnm, gprof)
+    dim = m.fb.calc_dim(gprof.width, gprof.height)
+    assert (dim.w, dim.h) == (1920, 1080)
+    nbins = dim.ah * dim.astride
+    tc = 0.5
+    ts, td = frame_times(gprof, tc)
+    g = rdr._handle(m.fb)
+    fronts, runs = [], []
+    for _ in range(2):
+        fid = C.c_uint32()
+        _lib.check(lib.fl_frame_begin(m.fb.ctx, C.byref(fid)))
+        m._copy(rdr, gnm)
+        _lib.check(lib.fl_interp(m.fb.ctx, g, dim.w, dim.h, ts, td))
+        run = C.c_uint64()
+        _lib.check(lib.fl_iterate(m.fb.ctx, g, dim.w, dim.h, float(2 ** 28), m.fuse, m.resolve_accum_mode(dim), C.byref(run)))
+        assert m.resolve_accum_mode(dim) == _lib.ACCUM_BINNED
+        fronts.append(m.fb.read('front', (nbins, 4), np.float32))
+        runs.append(run.value)
+    a, b = fronts
+    assert runs[0] >= 2 ** 28 and runs[0] - 2 ** 28 < m.fb.nslots * 256
+    da, db = density(a, dim), density(b, dim)
+    assert np.array_equal(da, np.rint(da)) and da.min() >= 0            # integer counts
+    assert da.sum() <= runs[0] and db.sum() <= runs[1]
+    assert not np.array_equal(da, db)
+    F = prepare(gnm, prof, tc)
+    ref, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], 2 ** 28, 16)
+    dr = density(ref, dim)
+    assert abs(da.sum() / runs[0] - dr.sum() / 2 ** 28) < 2e-3, (da.sum() / runs[0], dr.sum() / 2 ** 28)
+    H, W = dim.ah // 8 * 8, dim.astride // 8 * 8
+    def blocks(dd):
+        return dd[:H, :W].reshape(H // 8, 8, W // 8, 8).sum((1, 3))
+    ba, bb, br = blocks(da), blocks(db), blocks(dr)
+    assert np.abs(ba / ba.sum() - br / br.sum()).sum() < 0.02
+    s = br.sum() / ba.sum()
+    z = (ba * s - br) / np.sqrt(br + ba * s * s + 1.0)
+    assert z.std() < 1.3 and np.percentile(np.abs(z), 99.9) < 6.5 and np.abs(z).max() < 9.0, (z.std(), np.abs(z).max())
+    z2 = (ba - bb) / np.sqrt(ba + bb + 1.0)                              # frame vs frame: same estimator twice
+    assert z2.std() < 1.3 and np.abs(z2).max() < 9.0, (z2.std(), np.abs(z2).max())
+    ca, cr = a[:, :3].sum(0) / da.sum(), ref[:, :3].sum(0) / dr.sum()
+    assert np.abs(ca - cr).max() < 1.0 / 255
+
+    # full-size filter chain on frame b's accumulator (it is still the current front buffer)
+    d = O.calc_dim(gprof.width, gprof.height)
+    cur = b.copy()
+    vals = {}
+    for filt in rdr.filts:
+        vals[filt.name] = [float(v) for v in filt.scalars(gprof, getattr(gprof.filters, filt.name), dim, tc)]
+        filt.apply(m.fb, gprof, getattr(gprof.filters, filt.name), dim, tc)
+    dev = m.fb.read('front', (nbins, 4), np.float32)
+    assert [f.name for f in rdr.filts] == ['yuv', 'bilateral', 'logscale', 'colorclip']
+    cur = O.yuv_to_rgb(d, cur)
+    cur = O.bilateral_chain(d, cur, *vals['bilateral'])
+    cur = O.logscale(d, cur, *vals['logscale'])
+    cur = O.colorclip(d, cur, *vals['colorclip'])
+    assert np.isfinite(dev).all()
+    # tone-mapped values live in [0, 1]: 8 DE passes + log + gamma in fast math on both sides
+    err = np.abs(dev - cur)
+    assert err.max() < 2e-2 and err.mean() < 2e-4, (err.max(), err.mean())
+    assert np.percentile(err, 99.9) < 2e-3, np.percentile(err, 99.9)
+    m.fb.free()
