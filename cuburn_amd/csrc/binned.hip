@@ -40,6 +40,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan_b(uint32_t v, uint32_t) {    
 #define ACC_ILP 4
 #endif
 
+// TWL: log2 of the tile width (7: 128x64 tiles = 64 KB of LDS cells, two workgroups per CU;
+// 8: 256x64 tiles = 128 KB, for images with more than 2047 narrow tiles)
+template <uint32_t TWL>
 __global__ void __launch_bounds__(1024)
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
@@ -47,12 +50,13 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
               uint32_t nslots, uint32_t astride, uint32_t aheight)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *tile = reinterpret_cast<u64 *>(smem);                     // [FL_TILE_CELLS]
+    constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
+    u64 *tile = reinterpret_cast<u64 *>(smem);                     // [CELLS]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
 
-    for (uint32_t i = tid; i < FL_TILE_CELLS; i += blockDim.x) tile[i] = 0ull;
+    for (uint32_t i = tid; i < CELLS; i += blockDim.x) tile[i] = 0ull;
     __syncthreads();
 
     // this workgroup's contiguous range of batches
@@ -100,7 +104,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #pragma unroll
             for (int k = 0; k < ACC_ILP; ++k) {
                 if (!live[k]) continue;
-                const uint32_t off = rec[k] >> 8;                                // (ly << 7) | lx
+                const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
 #ifndef ACC_NOATOM
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
@@ -109,7 +113,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 if ((uint32_t)(old >> 32) >= (256u << 23)) {
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
-                        const uint32_t px = tx * FL_TILE_W + (off & 127u), py = ty * FL_TILE_H + (off >> 7);
+                        const uint32_t px = tx * TW + (off & (TW - 1u)), py = ty * FL_TILE_H + (off >> TWL);
                         spill_cell(cur, py * astride + px, out4);
                     }
                 }
@@ -120,9 +124,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 
     // add the tile to the global packed accumulator: one row segment of 64 cells per wave
     // instruction (coalesced atomics), draining cells that reach 512 hits
-    for (uint32_t i = tid; i < FL_TILE_CELLS; i += blockDim.x) {
+    for (uint32_t i = tid; i < CELLS; i += blockDim.x) {
         const u64 v = tile[i];
-        const uint32_t px = tx * FL_TILE_W + (i & 127u), py = ty * FL_TILE_H + (i >> 7);
+        const uint32_t px = tx * TW + (i & (TW - 1u)), py = ty * FL_TILE_H + (i >> TWL);
         if (v != 0ull && px < astride && py < aheight) {
             const uint32_t gi = py * astride + px;
             // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
@@ -141,8 +145,17 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
                         u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
-                        uint32_t astride, uint32_t aheight)
+                        uint32_t astride, uint32_t aheight, bool wide)
 {
-    hipLaunchKernelGGL(k_accum_tiles, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8, st, log, dir, palette, atom, out4,
+    if (wide) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024), (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8, st,
+                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
+        return;
+    }
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<7u>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8, st, log, dir, palette, atom, out4,
                        tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
 }

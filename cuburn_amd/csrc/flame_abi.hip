@@ -62,7 +62,7 @@ struct fl_ctx {
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
     float4 *d_points = nullptr;       // [nslots*NT]
     u64 *d_counters = nullptr;
-    uint32_t bin_rounds = 16, bin_parts = 16;
+    uint32_t bin_rounds = 16, bin_parts = 0;      // bin_parts 0: chosen per image (see do_iter_launch)
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
@@ -391,12 +391,17 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
 #define FL_BIN_MAX_ROUNDS 1024u
 
 static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint32_t *tiles_x, uint32_t *nbins,
-                         uint32_t *nbatch_total)
+                         uint32_t *nbatch_total, bool *wide)
 {
     const uint32_t nt = (uint32_t)c->nw * 64;
-    *tiles_x = (d.astride + 127) / 128;
-    *nbins = *tiles_x * ((d.ah + FL_TILE_H - 1) / FL_TILE_H);
-    if (*nbins > 2047) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 2047 tiles of 128x64)", __FILE__, __LINE__);
+    // 128x64 tiles while their number fits the 11 bits left in a staged record (up to 4K);
+    // larger images use 256x64 tiles with separately staged tile numbers
+    const uint32_t rows = (d.ah + FL_TILE_H - 1) / FL_TILE_H;
+    *wide = ((d.astride + 127) / 128) * rows > FL_MAX_BINS || getenv("FLAME_BIN_WIDE") != nullptr;
+    const uint32_t tw = *wide ? (1u << FL_TILE_W_WIDE_LOG2) : 128u;
+    *tiles_x = (d.astride + tw - 1) / tw;
+    *nbins = *tiles_x * rows;
+    if (*nbins > FL_MAX_BINS_WIDE) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 8191 tiles of 256x64)", __FILE__, __LINE__);
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
     size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
@@ -418,13 +423,14 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint
 static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count, int acc = 0)
 {
     uint32_t tiles_x = 0, nbins = 0, nbatch_total = 0;
+    bool wide = false;
     if (acc == FL_ACCUM_BINNED) {
         if (nrounds <= fuse) return fail(FL_E_INVAL, "binned launch needs write-enabled rounds", __FILE__, __LINE__);
-        int rc = ensure_binned(c, d, nrounds - fuse, &tiles_x, &nbins, &nbatch_total);
+        int rc = ensure_binned(c, d, nrounds - fuse, &tiles_x, &nbins, &nbatch_total, &wide);
         if (rc) return rc;
     }
     EvPair *e = ev_begin(c, c->iter_ev);
-    launch_iter(L(c).stream, c->nw, count, acc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
+    launch_iter(L(c).stream, c->nw, count, acc == FL_ACCUM_BINNED && wide ? 3 : acc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                 tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir);
     ev_end(c, e);
@@ -432,8 +438,12 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
         EvPair *e2 = ev_begin(c, c->flush_ev);
+        // workgroups per tile: enough of them to fill the chip several times over (~8192 in all),
+        // no more — every workgroup zeroes and drains a whole LDS tile whatever its share of records
+        uint32_t parts = c->bin_parts ? c->bin_parts : 8192u / nbins;
+        parts = parts < 1u ? 1u : parts > 16u ? 16u : parts;
         launch_accum_tiles(L(c).stream, L(c).d_log, L(c).d_dir, L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
-                           c->bin_parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah);
+                           parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
         ev_end(c, e2);
         HIPCHK(hipGetLastError());
     }

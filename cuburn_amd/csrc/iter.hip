@@ -113,7 +113,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t) {
 }
 
 // counters: [0] accepted, [1] out of frame, [2] dropped by hot-pixel roulette, [3] spills
-// ACC: 0 = packed global atomics, 1 = binned (sample log), 2 = none (measurement of the walk)
+// ACC: 0 = packed global atomics, 1 = binned (sample log, 128x64 tiles, tile number inside the staged
+// record), 2 = none (measurement of the walk), 3 = binned for images with more than 2047 tiles
+// (256x64 tiles, tile numbers staged in a separate 16-bit array)
 template <int NW, bool COUNT, int ACC>
 __global__ void __launch_bounds__(NW * 64)
 k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
@@ -124,12 +126,16 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
        uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir)
 {
     constexpr int NT = NW * 64;
+    constexpr bool BINNED = ACC == 1 || ACC == 3, WIDE = ACC == 3;
+    constexpr uint32_t TWL = WIDE ? FL_TILE_W_WIDE_LOG2 : 7u;          // log2 of the tile width
+    constexpr uint32_t PAY_BITS = TWL + FL_TILE_H_LOG2 + 8u;          // row | column | palette column
     // all LDS is carved from the dynamic region (16-byte aligned pieces)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float (*swp)[3][NT] = reinterpret_cast<float (*)[3][NT]>(smem);                    // [2][3][NT]
-    u64 *palrow = reinterpret_cast<u64 *>(smem + 2 * 3 * NT * 4);                      // [256]   (ACC != 1)
-    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (ACC == 1)
-    uint32_t *cnt = stage + bg.rounds * NT;                                            // [B+1]
+    u64 *palrow = reinterpret_cast<u64 *>(smem + 2 * 3 * NT * 4);                      // [256]   (not binned)
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (binned)
+    uint16_t *skey = reinterpret_cast<uint16_t *>(stage + bg.rounds * NT);             // [R*NT]  (wide only)
+    uint32_t *cnt = stage + bg.rounds * NT + (WIDE ? bg.rounds * NT / 2 : 0);          // [B+1]
     uint32_t *cur = cnt + ((bg.nbins + 1 + 3) & ~3u);                                  // [B+1]
     uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
 
@@ -139,8 +145,8 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     const int xf_off = prog[5], xf_stride = prog[6], var_stride = prog[7];
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
-    if (ACC != 1) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
-    if (ACC == 1) for (uint32_t i = tid; i <= bg.nbins; i += NT) cnt[i] = 0;
+    if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
+    if (BINNED) for (uint32_t i = tid; i <= bg.nbins; i += NT) cnt[i] = 0;
     uint32_t staged = 0, batch_in_slot = 0;
 
     const size_t wi = (size_t)slot * NT + tid;
@@ -210,13 +216,13 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         bool ok = (cx >= -0.5f) & (cx < fa_stride) & (cy >= -0.5f) & (cy < fa_height);     // NaN -> false; '&': no short-circuit branches
         // binned mode: a rejected sample only needs its tile number forced to "none" below, its
         // coordinate bits are never looked at, so they are not masked here
-        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok || ACC == 1 ? cx : 0.0f);
-        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok || ACC == 1 ? cy : 0.0f);
+        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok || BINNED ? cx : 0.0f);
+        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok || BINNED ? cy : 0.0f);
         if (COUNT) n_oob += !ok;
         const uint32_t gi = ok ? iy * astride + ix : 0u;
 
         float mult = 1.0f;
-        if (ok && ACC != 1) {                                               // iter.py:319-329
+        if (ok && !BINNED) {                                                // iter.py:319-329
             const uint32_t flag = (hot[gi >> 4] >> ((gi & 15u) << 1)) & 3u;
             if (flag) {
                 mult = hot_mult(flag);
@@ -225,7 +231,7 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         }
         const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
         const int ci = (int)__builtin_rintf(fminf(fmaxf(cf, 0.0f), 255.0f));
-        const u64 val = ACC == 1 ? 0ull : palrow[ci];                       // iter.py:351
+        const u64 val = BINNED ? 0ull : palrow[ci];                         // iter.py:351
 
         // Every add returns the previous cell value, but the value is only looked at one
         // round later (pend_*), so its latency hides under the next round's work.  A cell seen
@@ -236,11 +242,13 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
             drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
             pend_ok = ok; pend_gi = gi; pend_mult = mult;
             if (ok) pend_old = __hip_atomic_fetch_add(atom + gi, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (ACC == 1) {
+        } else if (BINNED) {
             // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
             // and written to this slot's private region of the sample log (no global atomics)
-            const uint32_t bin = ok ? __umul24(iy >> FL_TILE_H_LOG2, bg.tiles_x) + (ix >> 7) : bg.nbins;
-            const uint32_t rec = (bin << FL_REC_BITS) | ((iy & (FL_TILE_H - 1u)) << 15) | ((ix & 127u) << 8) | (uint32_t)ci;
+            const uint32_t bin = ok ? __umul24(iy >> FL_TILE_H_LOG2, bg.tiles_x) + (ix >> TWL) : bg.nbins;
+            const uint32_t pay = ((iy & (FL_TILE_H - 1u)) << (TWL + 8u)) | ((ix & ((1u << TWL) - 1u)) << 8) | (uint32_t)ci;
+            const uint32_t rec = WIDE ? pay : (bin << PAY_BITS) | pay;
+            if (WIDE) skey[staged * NT + tid] = (uint16_t)bin;
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (++staged == bg.rounds || rd + 1 == nrounds) {
@@ -249,9 +257,13 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                 // Each thread takes its own staged records into registers (while wave 0 scans the
                 // tile counts), so that the scatter below can sort the batch IN PLACE: no second
                 // R*NT buffer, which is what limits the workgroups per CU.
-                uint32_t r2[FL_BIN_R_MAX];
+                uint32_t r2[FL_BIN_R_MAX], k2[FL_BIN_R_MAX];       // payload, tile (0xffffffff: no record)
 #pragma unroll
-                for (int q = 0; q < FL_BIN_R_MAX; ++q) r2[q] = (uint32_t)q < staged ? stage[q * NT + tid] : 0xffffffffu;
+                for (int q = 0; q < FL_BIN_R_MAX; ++q) {
+                    const bool have = (uint32_t)q < staged;
+                    r2[q] = have ? stage[q * NT + tid] : 0u;
+                    k2[q] = !have ? 0xffffffffu : WIDE ? (uint32_t)skey[q * NT + tid] : r2[q] >> PAY_BITS;
+                }
                 if (w == 0) {                       // exclusive scan of the tile counts, directory entries
                     uint32_t running = 0;
                     for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
@@ -274,11 +286,11 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
                     uint32_t pos[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (r2[q0 + q] != 0xffffffffu)
-                            pos[q] = __hip_atomic_fetch_add(cur + (r2[q0 + q] >> FL_REC_BITS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k2[q0 + q] != 0xffffffffu)
+                            pos[q] = __hip_atomic_fetch_add(cur + k2[q0 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (r2[q0 + q] != 0xffffffffu) stage[pos[q]] = r2[q0 + q] & ((1u << FL_REC_BITS) - 1u);
+                        if (k2[q0 + q] != 0xffffffffu) stage[pos[q]] = r2[q0 + q] & ((1u << PAY_BITS) - 1u);
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;
@@ -378,7 +390,7 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
-    if (acc == 1) b += (size_t)rounds * nt * 4 + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
+    if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
     else b += FL_PAL_W * 8;
     return b;
 }
@@ -401,6 +413,10 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
     else if (acc == 1) {
         if (nw == 4) { if (count) LAUNCH(4, true, 1); else LAUNCH(4, false, 1); }
         else { if (count) LAUNCH(8, true, 1); else LAUNCH(8, false, 1); }
+    }
+    else if (acc == 3) {
+        if (nw == 4) { if (count) LAUNCH(4, true, 3); else LAUNCH(4, false, 3); }
+        else { if (count) LAUNCH(8, true, 3); else LAUNCH(8, false, 3); }
     }
     else if (nw == 4) { if (count) LAUNCH(4, true, 0); else LAUNCH(4, false, 0); }
     else if (nw == 8) { if (count) LAUNCH(8, true, 0); else LAUNCH(8, false, 0); }

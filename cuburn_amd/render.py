@@ -162,8 +162,9 @@ class Renderer(object):
 class RenderManager(object):
     """Frame queue (cuburn/render.py:253-434)."""
 
-    # 'auto': binned accumulate (sample log + LDS tiles) whenever the image has <= 2047 tiles of
-    # 128x64 pixels (up to 4K), else direct packed global atomics.  Both give the same histogram.
+    # 'auto': binned accumulate (sample log + LDS tiles: 128x64-pixel tiles up to 4K, 256x64 above)
+    # unless the image has more than 8191 tiles, else direct packed global atomics.  Both give the
+    # same histogram.
     accum_mode = 'auto'
     # Write-disabled iterations per walker at the start of a frame.  The reference's value is 256
     # (render.py:215: one whole round block, a by-product of its launch granularity); flam3 uses 15.
@@ -193,8 +194,9 @@ class RenderManager(object):
     def resolve_accum_mode(self, dim):
         mode = self.accum_mode
         if mode == 'auto':
-            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
-            mode = _lib.ACCUM_BINNED if ntiles <= 2047 else _lib.ACCUM_ATOMIC
+            # the library bins up to 8191 tiles of 256x64 pixels (128x64 up to 2047 tiles, i.e. 4K)
+            ntiles = ((dim.astride + 255) // 256) * ((dim.ah + 63) // 64)
+            mode = _lib.ACCUM_BINNED if ntiles <= 8191 else _lib.ACCUM_ATOMIC
         return mode
 
     def queue_frame(self, rdr, gnm, gprof, tc, copy=True):

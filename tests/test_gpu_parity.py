@@ -190,13 +190,17 @@ def test_iter_hot_pixels_and_spill(mgr):
     assert np.array_equal(dev_state[0], ref_state[0])
 
 
-def test_binned_equals_atomic_equals_oracle(mgr):
-    """The binned accumulate (LDS tile sort -> sample log -> LDS tile atomics -> coalesced packed
+@pytest.mark.parametrize('layout', ['narrow', 'wide'])
+def test_binned_equals_atomic_equals_oracle(mgr, layout, monkeypatch):
+    """(layout 'wide': the 256x64-tile variant used above 4K, forced here with FLAME_BIN_WIDE.)
+    The binned accumulate (LDS tile sort -> sample log -> LDS tile atomics -> coalesced packed
     adds) produces the same packed histogram, bit for bit, as direct global atomics and as the
     oracle: integer adds commute.  Odd round counts exercise a partial last batch."""
     gnm, prof = linear_flame()
     prof = dict(prof, width=1920, height=1080)
     gnm['camera']['scale'] = 1.0          # zoomed in: every cell stays below the 128-hit packed-add limit
+    if layout == 'wide':
+        monkeypatch.setenv('FLAME_BIN_WIDE', '1')
     res_a, ref_a, dev_a, dim, seeds = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=0)
     res_b, ref_b, dev_b, dim, _ = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=1, seeds_in=seeds)
     a, b = res_a[0], res_b[0]
@@ -208,9 +212,12 @@ def test_binned_equals_atomic_equals_oracle(mgr):
     assert np.array_equal(dev_a[0], dev_b[0]) and np.array_equal(dev_a[1][:, :3], dev_b[1][:, :3])
 
 
-def test_binned_hot_region_exact_density(mgr):
+@pytest.mark.parametrize('layout', ['narrow', 'wide'])
+def test_binned_hot_region_exact_density(mgr, layout, monkeypatch):
     """Binned mode on the hot-region flame, 3 launches: drains happen in LDS and at the tile add;
     density must still be exact against the oracle run without hot-pixel thinning."""
+    if layout == 'wide':
+        monkeypatch.setenv('FLAME_BIN_WIDE', '1')
     gnm, prof = hot_flame()
     res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=40, fuse=16, launches=3, mode=1)
     for k, r in enumerate(res):
@@ -513,21 +520,22 @@ def run_device_model_gpu_only(mgr, gnm, prof, nrounds, fuse, mode, seeds_in=None
     return dict(ctr=ctr, atom=atom), None, rng, dim, seeds0
 
 
-def test_8k_uses_direct_atomics(mgr):
-    """7680x4320 has 4148 tiles (> 2047): the binned mode refuses it, the shim's 'auto' picks atomics."""
-    lib = _lib.load()
+def test_8k_wide_binned_equals_atomic(mgr):
+    """7680x4320 has 4148 tiles of 128x64 (> 2047): the binned accumulate switches to 256x64 tiles
+    with separately staged tile numbers (2108 tiles) and still agrees with direct atomics bit for bit."""
     gnm, prof = linear_flame()
     prof = dict(prof, width=7680, height=4320)
-    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof)
-    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 1))
-    rc = lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, 0, 8, 4, 1)
-    assert rc == _lib.FL_E_UNSUPPORTED
-    _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, 0, 8, 4, 0))
-    ctr = np.zeros(4, np.uint64)
-    _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr.ctypes.data))
-    assert int(ctr[0]) + int(ctr[1]) == NSLOTS * 256 * 4
-    atom = mgr.fb.read('atom', (dim.ah * dim.astride,), np.uint64)
-    assert int((atom >> np.uint64(54)).sum()) == int(ctr[0])
+    gnm['camera']['scale'] = 0.6
+    res_a, _, dev_a, dim, seeds = run_device_model_gpu_only(mgr, gnm, prof, nrounds=19, fuse=5, mode=0)
+    res_b, _, dev_b, dim, _ = run_device_model_gpu_only(mgr, gnm, prof, nrounds=19, fuse=5, mode=1, seeds_in=seeds)
+    assert ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64) > 2047
+    assert np.array_equal(res_a['ctr'][:2], res_b['ctr'][:2])
+    assert int(res_a['ctr'][0]) > 0.3 * NSLOTS * 256 * 19
+    assert int(res_a['ctr'][3]) == 0
+    assert np.array_equal(res_a['atom'], res_b['atom'])
+    assert int((res_a['atom'] >> np.uint64(54)).sum()) == int(res_a['ctr'][0])
+    assert np.array_equal(dev_a, dev_b)
+    assert render.RenderManager.resolve_accum_mode(mgr, dim) == _lib.ACCUM_BINNED
 
 
 # ---------------------------------------------------------------------------------- sample sharding
