@@ -54,11 +54,14 @@ def cpu_baseline(gnm, prof, seconds):
     from common import O, prepare
     F = prepare(gnm, prof)
     cores = usable_cores()
-    probe = 1 << 21
-    _, secs, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], probe * cores, cores)
-    rate = probe * cores / max(secs, 1e-3)
-    n = int(max(probe * cores, min(2 ** 31, rate * seconds)))
-    _, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, cores)
+    # grow the sample until one run takes at least ~80 % of the budget (thread start-up makes
+    # short probes underestimate the rate), capped at 2^33 samples
+    n = (1 << 21) * cores
+    while True:
+        _, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, cores)
+        if secs >= 0.8 * seconds or n >= 2 ** 33:
+            break
+        n = int(min(2 ** 33, max(2 * n, n * seconds / max(secs, 1e-3))))
     return {'value': round(n / secs / 1e6, 3), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
             'sample': '%d samples of the cfg2 flame (1920x1080 histogram, per-thread private float4 '
                       'accumulators merged at the end), %.1f s wall' % (n, secs)}
