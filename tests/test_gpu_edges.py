@@ -1,0 +1,173 @@
+"""
+Edge cases of the hot path through the C ABI: smallest and ragged images, sample counts below one
+round, one xform and the maximum of 64, argument validation, the default filter chain, and state
+that must survive a change of image size.  The xform-choice tests use linear-only flames so that
+histograms are bit-exact against the oracle's device model.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import O, prepare, frame_times
+from cuburn_amd import configs, profile, render, _lib
+from cuburn_amd.packer import GenomePacker
+from test_gpu_parity import run_device_model, NSLOTS            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def mgr():
+    from __graft_entry__ import build
+    build()
+    return render.RenderManager(device=0, nslots=NSLOTS, host_seed=11)
+
+
+def nxf_flame(n, w=256, h=144):
+    """n linear xforms on a ring, unequal weights (the density table has n-1 entries)."""
+    gnm, prof = configs.cfg1()
+    xfs = {}
+    for i in range(n):
+        a = 2 * np.pi * i / max(n, 1)
+        xfs[str(i)] = {'weight': 0.2 + (i % 5) * 0.3, 'color': i / max(n - 1, 1), 'color_speed': 0.5,
+                       'pre_affine': configs._affine(7.0 * i, 0.45, 0.55 * float(np.cos(a)), 0.55 * float(np.sin(a))),
+                       'variations': {'linear': {'weight': 1.0}}}
+    gnm['xforms'] = xfs
+    return gnm, dict(prof, width=w, height=h)
+
+
+@pytest.mark.parametrize('n', [1, 2, 9, 33, 64])
+def test_xform_counts_bit_exact(mgr, n):
+    """1 xform (empty density table), more than 8 (the density table spans several lanes' worth of
+    the vector compare) and the maximum of 64: packed histogram, counters, RNG and walkers equal
+    the oracle's device model."""
+    gnm, prof = nxf_flame(n)
+    # One or two contracting maps are a point / a Cantor dust: a single cell takes tens of
+    # thousands of hits per round, which wraps the 10-bit count of the packed-atomic scheme (the
+    # reference's own limitation, iter.py:361-406) in an order-dependent way.  The binned
+    # accumulate is exact there; the atomic mode is compared from 9 xforms up.
+    for mode in ((1,) if n <= 2 else (0, 1)):
+        res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=6, fuse=3, launches=1, mode=mode)
+        r = res[0]
+        assert np.array_equal(r['ctr_dev'][:3], r['ctr_ref'][:3]), (n, mode, r['ctr_dev'], r['ctr_ref'])
+        assert int(r['ctr_dev'][0]) > 0
+        if int(r['ctr_dev'][3]) == 0 and int(r['ctr_ref'][3]) == 0:
+            assert np.array_equal(r['atom_dev'], r['atom_ref']), (n, mode)
+        # (one contracting xform is a single fixed point: its cell overflows and drains to the
+        # float accumulator, in an order that atomics do not fix; what is exact is the density)
+        assert np.array_equal(r['front_dev'][:, 3], r['front_ref'][:, 3]), (n, mode)
+        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=5e-5, atol=1e-3)   # float adds of drained chunks regroup
+        assert np.array_equal(dev_state[0], ref_state[0])
+        assert np.array_equal(dev_state[1][:, :3], ref_state[1][:, :3])
+
+
+def test_too_many_xforms_rejected():
+    gnm, prof = nxf_flame(65)
+    gprof = profile.wrap(prof, gnm)
+    with pytest.raises((ValueError, AssertionError)):
+        rdr = render.Renderer(gnm, gprof)
+        m = render.RenderManager(device=0, nslots=NSLOTS, host_seed=1)
+        try:
+            rdr._handle(m.fb)
+        finally:
+            m.fb.free()
+
+
+@pytest.mark.parametrize('w,h', [(1, 1), (33, 17), (8, 300), (1000, 999)])
+def test_ragged_sizes_render(mgr, w, h):
+    """calc_dim pads to (32, 16) multiples with a 12-pixel gutter (render.py:79-89); the whole
+    pipeline must work on any size and crop exactly the requested window."""
+    gnm, prof = configs.cfg2(samples=2 ** 22)
+    prof = dict(prof, width=w, height=h, spp=2 ** 22 / float(w * h) if w * h > 4096 else 400.0)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    evt, out = mgr.queue_frame(rdr, gnm, gprof, 0.5)
+    evt.synchronize()
+    out = np.array(out)
+    assert out.shape == (h, w, 4)
+    dim = mgr.fb.calc_dim(w, h)
+    d = O.calc_dim(w, h)
+    assert (dim.aw, dim.ah, dim.astride) == (d.aw, d.ah, d.astride)
+    assert dim.astride % 32 == 0 and dim.ah % 16 == 0 and dim.aw == w + 24
+    if w * h >= 33 * 17:
+        assert out[..., 3].max() > 0
+
+
+def test_sample_counts_below_one_round(mgr):
+    """nsamples 0, 1 and one short of a round all run exactly one write round (rounds are whole:
+    render.py:331-336 rounds the count up the same way)."""
+    lib = _lib.load()
+    gnm, prof = nxf_flame(3)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    dim = mgr.fb.calc_dim(gprof.width, gprof.height)
+    _lib.check(lib.fl_interp(mgr.fb.ctx, g, dim.w, dim.h, 0.5, 0.0))
+    per_round = NSLOTS * 256
+    for n, want in ((0.0, per_round), (1.0, per_round), (per_round - 1.0, per_round), (per_round + 1.0, 2 * per_round)):
+        for mode in (0, 1):
+            run = C.c_uint64()
+            _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, n, 4, mode, C.byref(run)))
+            assert run.value == want, (n, mode, run.value)
+            front = mgr.fb.read('front', (dim.ah * dim.astride, 4), np.float32)
+            assert 0 < front[:, 3].sum() <= want
+
+
+def test_argument_validation(mgr):
+    lib = _lib.load()
+    gnm, prof = nxf_flame(2)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    run = C.c_uint64()
+    assert lib.fl_iterate(mgr.fb.ctx, g, 256, 144, 1e6, 4, 7, C.byref(run)) == _lib.FL_E_INVAL        # bad mode
+    assert lib.fl_iterate(None, g, 256, 144, 1e6, 4, 0, C.byref(run)) == _lib.FL_E_INVAL              # null ctx
+    assert lib.fl_iterate(mgr.fb.ctx, None, 256, 144, 1e6, 4, 0, C.byref(run)) == _lib.FL_E_INVAL     # null genome
+    assert b'' != lib.fl_last_error()
+    vals = (C.c_float * 2)(1.0, 2.0)
+    assert lib.fl_filter(mgr.fb.ctx, _lib.FILT['bilateral'], 256, 144, vals, 2) == _lib.FL_E_INVAL    # too few scalars
+    assert lib.fl_filter(mgr.fb.ctx, 999, 256, 144, vals, 2) != 0
+    assert lib.fl_output(mgr.fb.ctx, 256, 144, 5, None, 0) == _lib.FL_E_INVAL                          # bad pixel format
+    ms = C.c_float()
+    assert lib.fl_frame_ms(mgr.fb.ctx, 0xfffffff0, C.byref(ms)) == _lib.FL_E_INVAL                     # untracked frame id
+    # fl_interp before any upload
+    rdr2 = render.Renderer(gnm, gprof)
+    m2 = render.RenderManager(device=0, nslots=NSLOTS, host_seed=3)
+    g2 = rdr2._handle(m2.fb)
+    assert lib.fl_interp(m2.fb.ctx, g2, 256, 144, 0.0, 0.0) == _lib.FL_E_INVAL
+    m2.fb.free()
+    # a corrupted program is rejected at creation
+    packer = GenomePacker(gnm)
+    prog = np.array(packer.prog, np.int32).copy()
+    prog[0] ^= 1
+    ops = np.ascontiguousarray(packer.ops_array, np.int32).reshape(-1)
+    h = C.c_void_p()
+    assert lib.fl_genome_create(mgr.fb.ctx, prog.ctypes.data, len(prog), ops.ctypes.data, len(ops) // 4,
+                                packer.nrows, C.byref(h)) == _lib.FL_E_INVAL
+
+
+def test_default_filter_chain_and_size_changes(mgr):
+    """The reference's default chain is bilateral -> logscale -> smearclip (specs.py:107); render it,
+    then a different size, then the first size again: buffers are re-sized, walkers / RNG persist, and
+    the two same-size frames agree within frame-to-frame noise."""
+    gnm, prof = configs.cfg2(samples=2 ** 24)
+    prof = dict(prof, width=320, height=200, spp=2 ** 24 / (320.0 * 200.0))
+    prof.pop('filter_order', None)
+    gprof = profile.wrap(prof, gnm)
+    assert list(gprof.filter_order) == ['bilateral', 'logscale', 'smearclip']
+    rdr = render.Renderer(gnm, gprof)
+    assert [f.name for f in rdr.filts] == ['yuv', 'bilateral', 'logscale', 'smearclip']
+    frames = []
+    for size in ((320, 200), (640, 64), (320, 200)):
+        p = dict(prof, width=size[0], height=size[1])
+        gp = profile.wrap(p, gnm)
+        rd = render.Renderer(gnm, gp)
+        evt, out = mgr.queue_frame(rd, gnm, gp, 0.5)
+        evt.synchronize()
+        out = np.array(out)
+        assert out.shape == (size[1], size[0], 4) and out[..., 3].max() > 100
+        frames.append(out.astype(np.float64))
+    assert np.abs(frames[0] - frames[2]).mean() < 6.0
+    assert not np.array_equal(frames[0], frames[2])
