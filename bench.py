@@ -100,7 +100,8 @@ def main():
     from cuburn_amd import configs, profile, render, _lib, distributed as D
     gnm, prof = configs.CONFIGS[args.config]()
     gprof = profile.wrap(prof, gnm)
-    mgr = render.RenderManager(device=local, nslots=int(os.environ.get('FLAME_NSLOTS', 1536)), host_seed=42 + rank)
+    nslots = int(os.environ['FLAME_NSLOTS']) if 'FLAME_NSLOTS' in os.environ else None     # None: chosen by image size
+    mgr = render.RenderManager(device=local, nslots=nslots, host_seed=42 + rank)
     mgr.accum_mode = _lib.ACCUM_BINNED if args.accum == 'binned' else _lib.ACCUM_ATOMIC
     if 'FLAME_FUSE' in os.environ:
         mgr.fuse = int(os.environ['FLAME_FUSE'])
@@ -154,7 +155,7 @@ def main():
     # (profiles/).  `value` above comes from the real two-lane pipeline.
     ksteps = max(2, min(args.steps, 4))
     os.environ['FLAME_LANES'] = '1'
-    kmgr = render.RenderManager(device=local, nslots=mgr.fb.nslots, host_seed=1042 + rank)
+    kmgr = render.RenderManager(device=local, nslots=nslots, host_seed=1042 + rank)
     del os.environ['FLAME_LANES']
     kmgr.accum_mode, kmgr.fuse = mgr.accum_mode, mgr.fuse
     krdr = render.Renderer(gnm, gprof)

@@ -175,12 +175,16 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
         c->own_stream = true;
     }
     c->nslots = nslots;
-    const char *env_nw = getenv("FLAME_NW");
-    if (env_nw && atoi(env_nw) == 8) c->nw = 8;
+    // waves per iterate workgroup (4 or 8) follow from the size of the seed table
+    {
+        const uint32_t fixed = FL_PAL_H * 256 + FL_NOUT;
+        const uint32_t per_wave = nslots * 64u;
+        if (nseeds == fixed + 8u * per_wave) c->nw = 8;
+        else if (nseeds != fixed + 4u * per_wave) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*64*NW + 64*256 + 65536 with NW = 4 or 8", __FILE__, __LINE__); }
+    }
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
     c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256 + FL_NOUT;
-    if (nseeds != c->nwalkers) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*nw*64 + 64*256 + 65536", __FILE__, __LINE__); }
     HIPCHK(hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers));
     HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * c->nw * 64));
     HIPCHK(hipMalloc(&c->d_counters, 8 * 4));

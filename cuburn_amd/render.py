@@ -62,19 +62,40 @@ class Framebuffers(object):
         astride = 32 * int(np.ceil(awidth / 32.))
         return Dimensions(width, height, awidth, aheight, astride)
 
-    def __init__(self, device=0, nslots=1536, host_seed=None, stream=None):
-        lib = _lib.load()
-        self.nslots = nslots
-        self.nw = 8 if os.environ.get('FLAME_NW') == '8' else 4       # waves per iterate workgroup
-        self.nthreads = self.nw * 64
+    # Walker geometry.  Up to 4K: 1536 slots of 4 waves (six 26 KB workgroups per CU).  Above
+    # (more than 2047 tiles of 128x64, where the accumulate uses its wide layout): 1024 slots of
+    # 8 waves — batches of 8192 samples halve the number of short runs per tile
+    # (cfg5 8K: 97 -> 80 ms per frame).  Explicit nslots / FLAME_NW pin the geometry.
+    NARROW, WIDE = (4, 1536), (8, 1024)
+
+    def __init__(self, device=0, nslots=None, host_seed=None, stream=None):
+        self.device, self.host_seed, self.stream = device, host_seed, stream
+        env_nw = os.environ.get('FLAME_NW')
+        self._auto = nslots is None and env_nw is None
+        self._cfg = (8 if env_nw == '8' else 4, nslots if nslots is not None else self.NARROW[1])
+        self._ctx = None
+        self.generation = 0                 # bumped whenever the native context is re-created
         self.nout = 65536                   # RNG states of the output dither kernel
-        self.nwalkers = nslots * self.nthreads + 64 * 256 + self.nout
-        seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, host_seed))
-        ctx = C.c_void_p()
-        _lib.check(lib.fl_ctx_create(device, stream, seeds.ctypes.data, self.nwalkers, nslots, C.byref(ctx)))
-        self.ctx = ctx
         self._host = {}
         self._pinned_ptrs = []
+        self.ctx                            # create now: no GPU / no library must fail here, loudly
+
+    nw = property(lambda self: self._cfg[0])             # waves per iterate workgroup
+    nslots = property(lambda self: self._cfg[1])
+    nthreads = property(lambda self: self._cfg[0] * 64)
+    nwalkers = property(lambda self: self.nslots * self.nthreads + 64 * 256 + self.nout)
+
+    @property
+    def ctx(self):
+        """The native context (re-created by set_dim when the image size asks for the other geometry)."""
+        if self._ctx is None:
+            lib = _lib.load()
+            seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, self.host_seed))
+            ctx = C.c_void_p()
+            _lib.check(lib.fl_ctx_create(self.device, self.stream, seeds.ctypes.data, self.nwalkers,
+                                         self.nslots, C.byref(ctx)))
+            self._ctx = ctx
+        return self._ctx
 
     def _pinned(self, shape, dtype):
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
@@ -95,7 +116,21 @@ class Framebuffers(object):
         return ring[-1]
 
     def set_dim(self, width, height, stream=None):
-        return self.calc_dim(width, height)
+        dim = self.calc_dim(width, height)
+        if self._auto:
+            ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
+            want = self.WIDE if ntiles > 2047 else self.NARROW
+            if want != self._cfg:
+                self._drop_ctx()
+                self._cfg = want
+        return dim
+
+    def _drop_ctx(self):
+        if self._ctx is not None:
+            _lib.load().fl_ctx_sync(self._ctx)
+            _lib.load().fl_ctx_destroy(self._ctx)
+            self._ctx = None
+            self.generation += 1
 
     def read(self, which, shape, dtype, genome=None):
         """Debug tap: copy a device buffer to the host."""
@@ -108,14 +143,13 @@ class Framebuffers(object):
         _lib.check(_lib.load().fl_write_buffer(self.ctx, genome, _lib.BUF[which], arr.ctypes.data, arr.nbytes))
 
     def free(self):
-        if self.ctx:
-            _lib.load().fl_ctx_sync(self.ctx)
-            self._host.clear()
-            for p in self._pinned_ptrs:
-                _lib.load().fl_host_free(p)
-            self._pinned_ptrs = []
-            _lib.load().fl_ctx_destroy(self.ctx)
-            self.ctx = None
+        if self._ctx is not None:
+            _lib.load().fl_ctx_sync(self._ctx)
+        self._host.clear()
+        for p in self._pinned_ptrs:
+            _lib.load().fl_host_free(p)
+        self._pinned_ptrs = []
+        self._drop_ctx()
 
     def __del__(self):
         try:
@@ -138,11 +172,17 @@ class Renderer(object):
     def __init__(self, gnm, gprof, keep=False, arch=None):
         self.packer, self.lib, self.cubin = self.compile(gnm, keep=keep, arch=arch)
         self.mod = None          # device handle, created on first use by a RenderManager
+        self._mod_key = None
         self.filts = filters.create(gprof)
         self.out = output.get_output_for_profile(gprof)
 
     def _handle(self, fb):
+        key = (id(fb), fb.generation)
+        if self.mod is not None and self._mod_key != key:      # the context it belonged to is gone
+            _lib.load().fl_genome_destroy(self.mod)
+            self.mod = None
         if self.mod is None:
+            self._mod_key = key
             g = C.c_void_p()
             prog = np.ascontiguousarray(self.packer.prog)
             ops = np.ascontiguousarray(self.packer.ops_array)
@@ -173,7 +213,7 @@ class RenderManager(object):
     # margin.  Set to 256 for the reference's literal schedule.
     fuse = 64
 
-    def __init__(self, device=None, nslots=1536, host_seed=None, stream=None):
+    def __init__(self, device=None, nslots=None, host_seed=None, stream=None):
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', 0)) if 'LOCAL_RANK' in os.environ else 0
         self.fb = Framebuffers(device, nslots, host_seed, stream)

@@ -137,9 +137,9 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
 /* cuburn/render.py:253-262 RenderManager.__init__ + :91-104 Framebuffers.__init__:
  * device, streams, walker/RNG state (persistent across frames, render.py:95-104).
  * `seeds` = nseeds x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
- * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536 with NW = waves per iterate workgroup
- * (4; 8 when the environment says FLAME_NW=8): walkers, then the palette kernel's states, then
- * the output dither's.  stream = a hipStream_t to run everything on (single lane), or NULL:
+ * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536, where NW = 4 or 8 is the number of
+ * waves per iterate workgroup (the table's size selects it): walkers, then the palette kernel's
+ * states, then the output dither's.  stream = a hipStream_t to run everything on (single lane), or NULL:
  * the context then owns two streams and alternates consecutive frames between them so that the
  * drain / filter / output work of frame k overlaps the iteration of frame k+1
  * (cuburn/render.py:432-433 swaps stream_a / stream_b the same way). */

@@ -171,3 +171,31 @@ def test_default_filter_chain_and_size_changes(mgr):
         frames.append(out.astype(np.float64))
     assert np.abs(frames[0] - frames[2]).mean() < 6.0
     assert not np.array_equal(frames[0], frames[2])
+
+
+def test_walker_geometry_follows_image_size():
+    """A manager built without an explicit slot count uses 1536 x 4-wave slots up to 4K and 1024 x
+    8-wave slots above (the native context is re-created on the switch, genome handles follow)."""
+    m = render.RenderManager(device=0, host_seed=5)
+    assert (m.fb.nw, m.fb.nslots) == (4, 1536)
+    gnm, prof = configs.cfg2(samples=2 ** 24)
+    small = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 24 / (640.0 * 360.0)), gnm)
+    big = profile.wrap(dict(prof, width=7680, height=4320, spp=2 ** 26 / (7680.0 * 4320.0)), gnm)
+    rdr_s, rdr_b = render.Renderer(gnm, small), render.Renderer(gnm, big)
+    gen0 = m.fb.generation
+    evt, a = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()
+    assert m.fb.generation == gen0 and np.array(a)[..., 3].max() > 0
+    evt, b = m.queue_frame(rdr_b, gnm, big, 0.5); evt.synchronize()
+    assert (m.fb.nw, m.fb.nslots) == (8, 1024) and m.fb.generation == gen0 + 1
+    b = np.array(b)
+    assert b.shape == (4320, 7680, 4) and b[..., 3].max() > 0
+    assert m.last_nsamples % (1024 * 512) == 0
+    evt, a2 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # same Renderer, new context
+    assert (m.fb.nw, m.fb.nslots) == (4, 1536) and m.fb.generation == gen0 + 2
+    a, a2 = np.array(a).astype(np.float64), np.array(a2).astype(np.float64)
+    assert np.abs(a - a2).mean() < 6.0
+    # an explicit slot count pins the geometry
+    p = render.RenderManager(device=0, nslots=NSLOTS, host_seed=5)
+    evt, _ = p.queue_frame(render.Renderer(gnm, big), gnm, big, 0.5); evt.synchronize()
+    assert (p.fb.nw, p.fb.nslots) == (4, NSLOTS)
+    m.fb.free(); p.fb.free()
