@@ -6,6 +6,9 @@
 // path worth using for this, so taps are explicit clamped loads.
 #include "flame_device.h"
 #include "kernels.h"
+#include <utility>
+#include <type_traits>
+#include <cstdlib>
 
 // cuburn/code/filters.py:8-17
 __constant__ float2 shear_patterns[16] = {
@@ -413,6 +416,166 @@ k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed-math form of the LDS-tiled DE pass.  A thread owns the two pixels (i, y) and (i+16, y)
+// of the 32x16 tile and evaluates their taps in lockstep on float2 values,
+// so the adds / multiplies / fmas of a tap issue as v_pk_*_f32 (two FP32 operations per lane and
+// instruction on CDNA3/4) — the scalar form is VALU-issue bound.  For the two pixels' values to
+// arrive as a register pair without moves the tile is staged as six planes (x, y, z, w, w^dpow,
+// 1/(avg+1e-6)) interleaved by row ([row][plane][column]): the pair is then two floats of one
+// plane 16 apart = one ds_read2_b32 at any tap offset.  The row stride is padded to 16 (mod 64)
+// floats: the 16 lanes of a row read 16 consecutive banks, the four rows a wave touches fall on
+// the four disjoint bank groups, in both halves of the read — no bank conflicts.
+#ifndef DE_PK_GROUP
+#define DE_PK_GROUP 2
+#endif
+#ifndef DE_PK_WAVES
+#define DE_PK_WAVES 4
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 f2u __attribute__((aligned(4)));
+__device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int PATTERN> __host__ __device__ __forceinline__ constexpr int de_pk_row_stride() {
+    int rs = 6 * (DE_TW + 2 * de_hx<PATTERN>());
+    while (rs % 64 != 16) ++rs;
+    return rs;
+}
+
+template <int PATTERN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DE_PK_WAVES, DE_PK_WAVES)))
+k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRout, float *__restrict__ Wout,
+                  const float4 *__restrict__ N, const float2 *__restrict__ PR,
+                  float sstd, float cstd, float dstd, float dpow, float gspeed)
+{
+    constexpr int HX = de_hx<PATTERN>(), HY = de_hy<PATTERN>();
+    constexpr int LW = DE_TW + 2 * HX, LH = DE_TH + 2 * HY;
+    constexpr int RS = de_pk_row_stride<PATTERN>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *pl = reinterpret_cast<float *>(smem);                         // [LH][6][LW] (+ row padding)
+
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * DE_TW, by0 = blockIdx.y * DE_TH;
+    constexpr int NIT = (LH * LW + 255) / 256;
+    float4 tn[NIT];
+    float2 tp[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = min(it * 256 + tid, LH * LW - 1);
+        const int ly = idx / LW, lx = idx - ly * LW;
+        const int gx = min(max(bx0 + lx - HX, 0), (int)d.astride - 1);
+        const int gy = min(max(by0 + ly - HY, 0), (int)d.ah - 1);
+        const uint32_t g = (uint32_t)(gy * (int)d.astride + gx);
+        tn[it] = N[g];
+        tp[it] = PR[g];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        if (idx < LH * LW) {
+            const int ly = idx / LW, lx = idx - ly * LW;
+            float *row = pl + ly * RS + lx;
+            row[0] = tn[it].x; row[LW] = tn[it].y; row[2 * LW] = tn[it].z; row[3 * LW] = tn[it].w;
+            row[4 * LW] = tp[it].x; row[5 * LW] = tp[it].y;
+        }
+    }
+    const float cs2 = frcp(-FM_SQRT2 * 3.0f * cstd) * FM_LOG2E;
+    const float ds = fdiv(-0.5f, dstd);
+    __syncthreads();
+
+    float spk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float df = (float)k;
+        spk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fexp(fdiv(df * df, -FM_SQRT2 * sstd)))));
+    }
+
+    const int ox = tid & 15, oy = tid >> 4;                  // pixels (ox, oy) and (ox + 16, oy)
+    // byte address of the centre of pixel A in plane 0 (dynamic LDS starts at the kernel's LDS base)
+    uint32_t ctr = (uint32_t)(size_t)pl + (uint32_t)(((oy + HY) * RS + ox + HX) * 4);
+
+    // One ds_read2_b32 brings the pair (plane[p], plane[p + 16]) into an aligned register pair.
+    // The compiler's own pairing of LDS reads follows program order, not this pixel pairing, so
+    // the reads are written out; they complete asynchronously and are waited for by the
+    // "s_waitcnt lgkmcnt(0)" at the top of the step that consumes them (see STEP below).
+#define RD2(dst, addr, o0) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"((o0) + 16))
+    // pairs needed before the loop, read the ordinary way
+    const float *c0 = pl + (oy + HY) * RS + ox + HX;
+#define CPAIR(k, r) ((f2){c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r)], c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r) + 16]})
+    const f2 cw = CPAIR(3, 0);
+    const f2 cfix = cw * (f2){frcp(cw.x + 1.0e-6f), frcp(cw.y + 1.0e-6f)};
+    const f2 cx = CPAIR(0, 0) * cfix, cy = CPAIR(1, 0) * cfix, cz = CPAIR(2, 0) * cfix;
+    const f2 cpow = CPAIR(4, 0);
+    const bool liveA = cw.x > 0.0f, liveB = cw.y > 0.0f;
+    f2 outx = 0.0f, outy = 0.0f, outz = 0.0f, outw = 0.0f, wsum = 0.0f;
+    f2 wprev = CPAIR(3, -16);
+    f2 px = CPAIR(0, -15), py = CPAIR(1, -15), pz = CPAIR(2, -15), pw = CPAIR(3, -15);
+#undef CPAIR
+
+    // Software pipeline, two taps per step, double-buffered: step g waits for the reads issued
+    // in step g-1 (buffer g&1), issues the reads of step g+1, then does the arithmetic of its two
+    // taps.  Every value that must not be touched early goes through the waiting asm.
+    f2 L[2][2][6];                     // [buffer][tap][next x, next y, next z, next w, p, q]
+    auto issue = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+#define ISSUE_TAP(k) if constexpr (-15 + g * 2 + (k) <= 15) { \
+            constexpr int r = -15 + g * 2 + (k); \
+            const uint32_t an = ctr + (uint32_t)((tap_dy<PATTERN>(r + 1) * RS + tap_dx<PATTERN>(r + 1)) * 4); \
+            const uint32_t ap = ctr + (uint32_t)((tap_dy<PATTERN>(r) * RS + tap_dx<PATTERN>(r) + 4 * LW) * 4); \
+            RD2(L[g & 1][k][0], an, 0); RD2(L[g & 1][k][1], an, LW); RD2(L[g & 1][k][2], an, 2 * LW); RD2(L[g & 1][k][3], an, 3 * LW); \
+            RD2(L[g & 1][k][4], ap, 0); RD2(L[g & 1][k][5], ap, LW); }
+        ISSUE_TAP(0) ISSUE_TAP(1)
+#undef ISSUE_TAP
+    };
+    auto step = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        f2 (&T)[2][6] = L[g & 1];
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(T[0][0]), "+v"(T[0][1]), "+v"(T[0][2]), "+v"(T[0][3]), "+v"(T[0][4]), "+v"(T[0][5]),
+                       "+v"(T[1][0]), "+v"(T[1][1]), "+v"(T[1][2]), "+v"(T[1][3]), "+v"(T[1][4]), "+v"(T[1][5]),
+                       "+v"(ctr), "+v"(wsum), "+v"(outx), "+v"(outy), "+v"(outz), "+v"(outw));
+        if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
+        asm volatile("" : "+v"(px), "+v"(pw));      // the arithmetic below starts after the reads above are issued
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = -15 + g * 2 + k;
+            if (r <= 15) {
+                const f2 yd = px - cx, ud = py - cy, vd = pz - cz;
+                f2 cdiff = f2fma(vd, vd, f2fma(ud, ud, yd * yd));
+                cdiff.x = (pw.x > 0.0f && liveA) ? cdiff.x : 0.5f;
+                cdiff.y = (pw.y > 0.0f && liveB) ? cdiff.y : 0.5f;
+                const f2 ad = cpow - T[k][4];
+                f2 e = f2fma((f2)ds, __builtin_elementwise_max(ad, -ad), cdiff * cs2);
+                if (r != 0) {
+                    const f2 gr = (T[k][3] - wprev) * T[k][5] * (r < 0 ? -gspeed : gspeed);
+                    e -= (f2){fexp2(gr.x), fexp2(gr.y)};
+                }
+                const f2 factor = (f2){fexp2(e.x), fexp2(e.y)} * spk[r < 0 ? -r : r];
+                wsum += factor;
+                const f2 fw = factor * pw;
+                outx = f2fma(fw, px, outx); outy = f2fma(fw, py, outy); outz = f2fma(fw, pz, outz); outw += fw;
+                wprev = pw;
+                px = T[k][0]; py = T[k][1]; pz = T[k][2]; pw = T[k][3];
+            }
+        }
+    };
+    issue(std::integral_constant<int, 0>{});
+    [&]<int... G>(std::integer_sequence<int, G...>) __attribute__((always_inline)) {
+        (step(std::integral_constant<int, G>{}), ...);
+    }(std::make_integer_sequence<int, 16>{});
+#undef RD2
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float ow = h ? outw.y : outw.x, ws = h ? wsum.y : wsum.x;
+        const float sx = h ? outx.y : outx.x, sy = h ? outy.y : outy.x, sz = h ? outz.y : outz.x;
+        const float wn = ow * frcp(ws + 1e-10f);
+        const float rn = ow >= 1.17549435e-38f ? frcp(ow) : 0.0f;       // v_rcp_f32 of a denormal is +inf
+        const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox + 16 * h);
+        Nout[go] = make_float4(sx * rn, sy * rn, sz * rn, wn);
+        PRout[go].x = fpow(wn, dpow);
+        Wout[go] = wn;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float *__restrict__ W,
            const float4 *__restrict__ src, float dpow)
@@ -657,6 +820,16 @@ void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, cons
 }
 void launch_den_blur_1c_rcp2(hipStream_t st, fl_dim d, float *PR, const float *src, int p, int up, const float *c) { hipLaunchKernelGGL(k_den_blur_1c_rcp2, GRID(d), 0, st, d, (float2 *)PR, src, p, up, mk(c)); }
 template <int P>
+static void launch_de_pk_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
+                             float sstd, float cstd, float dstd, float dpow, float gspeed) {
+    constexpr int LH = DE_TH + 2 * de_hy<P>();
+    const size_t lds = (size_t)LH * de_pk_row_stride<P>() * 4;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void *)k_de_bilateral_pk<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_de_bilateral_pk<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, Wout, N, PR,
+                       sstd, cstd, dstd, dpow, gspeed);
+}
+template <int P>
 static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
                               float sstd, float cstd, float dstd, float dpow, float gspeed) {
     constexpr int LW = DE_TW + 2 * de_hx<P>(), LH = DE_TH + 2 * de_hy<P>();
@@ -668,7 +841,9 @@ static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PR
 }
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
                              float sstd, float cstd, float dstd, float dpow, float gspeed) {
-#define DE(P) case P: launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
+    const bool pk = getenv("FLAME_DE_LDS_AOS") == nullptr;      // default: packed-math form; FLAME_DE_LDS_AOS=1: scalar-math form
+#define DE(P) case P: if (!pk) launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); \
+                      else launch_de_pk_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
 }
