@@ -94,7 +94,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        # FLAME_BENCH_BACKEND=gloo + FLAME_BENCH_DEVICE=k: dry run of the multi-rank control flow on
+        # a box with fewer GPUs than ranks (every rank renders on device k, collectives on CPU tensors)
+        backend = os.environ.get('FLAME_BENCH_BACKEND', 'nccl')
+        if 'FLAME_BENCH_DEVICE' in os.environ:
+            local = int(os.environ['FLAME_BENCH_DEVICE'])
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = 'cuda' if world == 1 or dist.get_backend() == 'nccl' else 'cpu'
     torch.cuda.set_device(local)
 
     from cuburn_amd import configs, profile, render, _lib, distributed as D
@@ -107,7 +116,7 @@ def main():
         mgr.fuse = int(os.environ['FLAME_FUSE'])
     rdr = render.Renderer(gnm, gprof)
     w, h = gprof.width, gprof.height
-    frame = torch.empty((h, w, 4), dtype=torch.uint8, device='cuda')
+    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=coll_dev)
     gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
     tc = 0.5
 
@@ -169,12 +178,12 @@ def main():
     acc['steps'] = ksteps
     fence()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     job_samples_per_step = mgr.last_nsamples * world            # frames: every rank runs the same workload
     if world > 1 and args.shard == 'samples':
-        ns = torch.tensor([mgr.last_nsamples], dtype=torch.float64, device='cuda')
+        ns = torch.tensor([mgr.last_nsamples], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(ns)
         job_samples_per_step = int(ns.item())
 
@@ -206,7 +215,7 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
-                       'samples_per_frame': mgr.last_nsamples, 'stream_lanes': 2,
+                       'samples_per_frame': mgr.last_nsamples if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
                        'parallelism': ('frame-sharded x%d, RCCL gather' if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators') % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
