@@ -36,6 +36,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan_b(uint32_t v, uint32_t) {    
     return v;
 }
 
+// Wave-level synchronisation point for the compiler (no instruction: a wave's LDS operations
+// execute in order).  Lanes of one wave communicating through LDS are, to the compiler, distinct
+// threads racing on plain memory; the fences make the exchange well-defined.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {                // same DPP steps, max instead of add
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 #ifndef ACC_ILP
 #define ACC_ILP 4
 #endif
@@ -52,11 +71,13 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
     u64 *tile = reinterpret_cast<u64 *>(smem);                     // [CELLS]
+    uint32_t *mk = reinterpret_cast<uint32_t *>(smem + CELLS * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
 
     for (uint32_t i = tid; i < CELLS; i += blockDim.x) tile[i] = 0ull;
+    mk[lane] = 0u;
     __syncthreads();
 
     // this workgroup's contiguous range of batches
@@ -72,26 +93,44 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
         const uint32_t total = __shfl(incl, 63);
+        // Which run does record v of the virtual array belong to?  Every non-empty run drops a
+        // mark (run number | source offset - v) at its first position; a max-scan over the
+        // positions (DPP, pure VALU) then carries the latest mark to every position.  This
+        // replaces a 6-step shuffle binary search + two more shuffles per record (8 trips through
+        // the LDS pipe) by one predicated LDS write, one read and one clear per 64 records.
+        uint32_t carry = 0;
         for (uint32_t v0 = 0; v0 < total; v0 += 64 * ACC_ILP) {
             uint32_t rec[ACC_ILP], row[ACC_ILP];
             bool live[ACC_ILP];
 #pragma unroll
             for (int k = 0; k < ACC_ILP; ++k) {
-                const uint32_t v = v0 + k * 64 + lane;
-                // rightmost run r with excl[r] <= v (binary search over the 64 lanes' values)
-                uint32_t r = 0;
-#ifndef ACC_NOSEARCH
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) {
-                    const uint32_t probe = r + step;
-                    const uint32_t pe = __shfl(excl, probe & 63);
-                    if (probe < 64 && pe <= v) r = probe;
+                const uint32_t lo = v0 + k * 64, v = lo + lane;
+                if (c != 0u && excl - lo < 64u) mk[excl - lo] = (lane << 24) | ((first - excl) & 0xffffffu);
+                wave_sync();                 // lanes exchange data through LDS: without it the compiler
+                uint32_t m = mk[lane];       // forwards this lane's own earlier "= 0" into the load
+                wave_sync();
+                mk[lane] = 0u;
+                m = wave_incl_maxscan(m);
+                m = max(m, carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+                const uint32_t r = m >> 24;
+                const int delta = (int)(m << 8) >> 8;                         // first[r] - excl[r], sign-extended
+                live[k] = v < total;
+#ifdef ACC_DEBUG
+                {
+                    uint32_t r2 = 0;
+                    for (int step = 32; step >= 1; step >>= 1) { const uint32_t probe = r2 + step; const uint32_t pe = __shfl(excl, probe & 63); if (probe < 64 && pe <= v) r2 = probe; }
+                    const int d2 = (int)__shfl(first, r2) - (int)__shfl(excl, r2);
+                    if (live[k] && (r2 != r || d2 != delta)) {
+                        if (atomicAdd((unsigned *)(out4 + 0), 1u) == 0u) {
+                            ((unsigned *)out4)[1] = v; ((unsigned *)out4)[2] = (r2 << 16) | r; ((unsigned *)out4)[3] = (unsigned)delta; ((unsigned *)out4)[4] = (unsigned)d2;
+                            ((unsigned *)out4)[5] = m; ((unsigned *)out4)[6] = carry; ((unsigned *)out4)[7] = total;
+                        }
+                    }
                 }
 #endif
-                const uint32_t r_excl = __shfl(excl, r), r_first = __shfl(first, r);
-                live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
-                rec[k] = live[k] ? log[(size_t)rbatch * batch_records + r_first + (v - r_excl)] : 0u;
+                rec[k] = live[k] ? log[(size_t)rbatch * batch_records + (uint32_t)((int)v + delta)] : 0u;
                 row[k] = ((rbatch % nslots) % FL_NTEMPORAL) >> 4;
             }
             u64 val[ACC_ILP];
@@ -150,12 +189,12 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
     if (wide) {
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024), (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8, st,
+        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024), (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4, st,
                            log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
         return;
     }
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<7u>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8, st, log, dir, palette, atom, out4,
+    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8 + 1024 * 4, st, log, dir, palette, atom, out4,
                        tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
 }
