@@ -497,7 +497,7 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
     // The compiler's own pairing of LDS reads follows program order, not this pixel pairing, so
     // the reads are written out; they complete asynchronously and are waited for by the
     // "s_waitcnt lgkmcnt(0)" at the top of the step that consumes them (see STEP below).
-#define RD2(dst, addr, o0) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"((o0) + 16))
+#define RD2(dst, addr, o0) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"((o0) + 16) : "memory")
     // pairs needed before the loop, read the ordinary way
     const float *c0 = pl + (oy + HY) * RS + ox + HX;
 #define CPAIR(k, r) ((f2){c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r)], c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r) + 16]})
