@@ -116,39 +116,18 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 const uint32_t r = m >> 24;
                 const int delta = (int)(m << 8) >> 8;                         // first[r] - excl[r], sign-extended
                 live[k] = v < total;
-#ifdef ACC_DEBUG
-                {
-                    uint32_t r2 = 0;
-                    for (int step = 32; step >= 1; step >>= 1) { const uint32_t probe = r2 + step; const uint32_t pe = __shfl(excl, probe & 63); if (probe < 64 && pe <= v) r2 = probe; }
-                    const int d2 = (int)__shfl(first, r2) - (int)__shfl(excl, r2);
-                    if (live[k] && (r2 != r || d2 != delta)) {
-                        if (atomicAdd((unsigned *)(out4 + 0), 1u) == 0u) {
-                            ((unsigned *)out4)[1] = v; ((unsigned *)out4)[2] = (r2 << 16) | r; ((unsigned *)out4)[3] = (unsigned)delta; ((unsigned *)out4)[4] = (unsigned)d2;
-                            ((unsigned *)out4)[5] = m; ((unsigned *)out4)[6] = carry; ((unsigned *)out4)[7] = total;
-                        }
-                    }
-                }
-#endif
                 const uint32_t rbatch = g0 + r;
                 rec[k] = live[k] ? log[(size_t)rbatch * batch_records + (uint32_t)((int)v + delta)] : 0u;
                 row[k] = ((rbatch % nslots) % FL_NTEMPORAL) >> 4;
             }
             u64 val[ACC_ILP];
 #pragma unroll
-#ifndef ACC_NOPAL
             for (int k = 0; k < ACC_ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
-#else
-            for (int k = 0; k < ACC_ILP; ++k) val[k] = (1ull << 54) | rec[k];
-#endif
 #pragma unroll
             for (int k = 0; k < ACC_ILP; ++k) {
                 if (!live[k]) continue;
                 const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
-#ifndef ACC_NOATOM
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-                const u64 old = val[k]; if (off == 0x7fffffff) tile[0] = old;
-#endif
                 if ((uint32_t)(old >> 32) >= (256u << 23)) {
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
