@@ -62,11 +62,13 @@ class Framebuffers(object):
         astride = 32 * int(np.ceil(awidth / 32.))
         return Dimensions(width, height, awidth, aheight, astride)
 
-    # Walker geometry.  Up to 4K: 1536 slots of 4 waves (six 26 KB workgroups per CU).  Above
-    # (more than 2047 tiles of 128x64, where the accumulate uses its wide layout): 1024 slots of
-    # 8 waves — batches of 8192 samples halve the number of short runs per tile
-    # (cfg5 8K: 97 -> 80 ms per frame).  Explicit nslots / FLAME_NW pin the geometry.
+    # Walker geometry.  Small images: 1536 slots of 4 waves (six 26 KB workgroups per CU).  From
+    # about 1440p up (more than 1024 tiles of 128x64) 1024 slots of 8 waves: batches of 8192
+    # samples keep the runs per tile long enough for the accumulate (cfg4 4K: 5.61 -> 5.49 ms,
+    # cfg5 8K: 97 -> 79 ms per frame; at 1080p the 4-wave geometry is 3 % faster).  Explicit
+    # nslots / FLAME_NW pin the geometry.
     NARROW, WIDE = (4, 1536), (8, 1024)
+    WIDE_FROM_TILES = 1024
 
     def __init__(self, device=0, nslots=None, host_seed=None, stream=None):
         self.device, self.host_seed, self.stream = device, host_seed, stream
@@ -119,7 +121,7 @@ class Framebuffers(object):
         dim = self.calc_dim(width, height)
         if self._auto:
             ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
-            want = self.WIDE if ntiles > 2047 else self.NARROW
+            want = self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
             if want != self._cfg:
                 self._drop_ctx()
                 self._cfg = want

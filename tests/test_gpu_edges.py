@@ -174,8 +174,9 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 
 def test_walker_geometry_follows_image_size():
-    """A manager built without an explicit slot count uses 1536 x 4-wave slots up to 4K and 1024 x
-    8-wave slots above (the native context is re-created on the switch, genome handles follow)."""
+    """A manager built without an explicit slot count uses 1536 x 4-wave slots for small images and
+    1024 x 8-wave slots from ~1440p up (the native context is re-created on the switch, genome
+    handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)
     assert (m.fb.nw, m.fb.nslots) == (4, 1536)
     gnm, prof = configs.cfg2(samples=2 ** 24)
