@@ -15,7 +15,7 @@ for cfgname in sys.argv[1:] or ['cfg2']:
     for mode in [int(m) for m in os.environ.get('MODES', '0,2,1').split(',')]:
         mgr.timings_reset()
         run = C.c_uint64()
-        _lib.check(lib.fl_iterate(mgr.fb.ctx, g, 1920, 1080, float(2 ** 28), 256, mode, C.byref(run)))
+        _lib.check(lib.fl_iterate(mgr.fb.ctx, g, 1920, 1080, float(2 ** 28), 64, mode, C.byref(run)))
         t = mgr.timings()
         print(cfgname, 'mode', mode, 'iter %.3f ms  %.1f Gsamples/s (incl. fuse rounds: %.1f Giter/s)' % (
-            t['iter_ms'], run.value / t['iter_ms'] / 1e6, (run.value + 256 * mgr.fb.nslots * 256) / t['iter_ms'] / 1e6))
+            t['iter_ms'], run.value / t['iter_ms'] / 1e6, (run.value + 64 * mgr.fb.nslots * 256) / t['iter_ms'] / 1e6))
