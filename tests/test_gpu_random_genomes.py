@@ -1,0 +1,146 @@
+"""
+Randomised genomes through the C ABI: the structure of the genome is data here (one precompiled
+interpreter kernel), so parity must hold for ANY structure, not just the BASELINE configs.
+A seeded generator draws xform counts, variation sets (with parameters), post affines, final
+xforms, animated ([p0, v0, p1, v1] + extra knots) splines and two palettes; for each genome:
+  * the 1024 interpolated parameter blocks agree with the oracle's by-name float64 restatement;
+  * every word of the block that is not a spline / precalc value is exactly the structure the
+    program says (variation numbers, counts, zero padding);
+  * a short iterate lands the same fraction of samples in frame as the oracle's flam3-style game
+    driven by the ORACLE's parameter blocks, with matching mean colour (distributional, since
+    random variations use hardware transcendentals).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import O, prepare, frame_times
+from cuburn_amd import configs, profile, render, _lib
+from cuburn_amd.genome import variations as V
+
+pytestmark = pytest.mark.gpu
+NSLOTS = 1024
+
+# variations that are safe to draw at random weights (bounded output for bounded input or
+# at least not systematically divergent); the full set is covered one by one in
+# test_gpu_variations.py
+POOL = ['linear', 'sinusoidal', 'spherical', 'swirl', 'horseshoe', 'polar', 'handkerchief', 'heart', 'disc',
+        'spiral', 'hyperbolic', 'diamond', 'ex', 'julia', 'bent', 'waves', 'fisheye', 'popcorn', 'power',
+        'cosine', 'rings', 'fan', 'blob', 'pdj', 'fan2', 'rings2', 'eyefish', 'bubble', 'cylinder',
+        'perspective', 'julian', 'juliascope', 'ngon', 'curl', 'rectangles', 'tangent', 'cross', 'cell',
+        'bipolar', 'wedge', 'scry', 'split', 'stripes', 'waves2', 'mobius', 'flux']
+
+
+@pytest.fixture(scope='module')
+def mgr():
+    from __graft_entry__ import build
+    build()
+    return render.RenderManager(device=0, nslots=NSLOTS, host_seed=23)
+
+
+def random_spline(rs, lo, hi, animated):
+    a = float(rs.uniform(lo, hi))
+    if not animated or rs.rand() < 0.5:
+        return a
+    b = float(rs.uniform(lo, hi))
+    span = hi - lo
+    knots = [a, float(rs.uniform(-0.3, 0.3) * span), b, float(rs.uniform(-0.3, 0.3) * span)]
+    if rs.rand() < 0.4:                      # an interior knot
+        knots += [float(rs.uniform(0.2, 0.8)), float(rs.uniform(lo, hi))]
+    return knots
+
+
+def random_genome(seed):
+    rs = np.random.RandomState(seed)
+    animated = seed % 2 == 1
+    nxf = int(rs.randint(1, 13))
+    xforms = {}
+    for i in range(nxf):
+        names = list(rs.choice([n for n in POOL if n in V.var_ids], size=int(rs.randint(1, 4)), replace=False))
+        if rs.rand() < 0.5 and 'linear' not in names:
+            names.append('linear')
+        var = {}
+        for n in names:
+            var[n] = {'weight': random_spline(rs, 0.2, 0.9, animated)}
+            for p, (dflt, interp) in V.var_params[n].items():
+                if p != 'weight' and rs.rand() < 0.7:
+                    base = dflt if dflt else 0.5
+                    var[n][p] = random_spline(rs, 0.5 * base, 1.5 * base, animated) if interp == 'mag' else \
+                        random_spline(rs, -abs(base), abs(base), animated)
+        xf = {'weight': random_spline(rs, 0.1, 1.0, animated), 'color': random_spline(rs, 0.0, 1.0, animated),
+              'color_speed': random_spline(rs, 0.1, 0.9, animated),
+              'pre_affine': configs._affine(float(rs.uniform(-180, 180)), float(rs.uniform(0.3, 0.8)),
+                                            float(rs.uniform(-0.6, 0.6)), float(rs.uniform(-0.5, 0.5))),
+              'variations': var}
+        if animated and rs.rand() < 0.5:
+            xf['pre_affine']['angle'] = [xf['pre_affine']['angle'], float(rs.uniform(-90, 90)),
+                                         xf['pre_affine']['angle'] + float(rs.uniform(-60, 60)), float(rs.uniform(-90, 90))]
+        if rs.rand() < 0.4:
+            xf['post_affine'] = configs._affine(float(rs.uniform(-30, 30)), float(rs.uniform(0.8, 1.1)),
+                                                float(rs.uniform(-0.1, 0.1)), float(rs.uniform(-0.1, 0.1)))
+        xforms[str(i)] = xf
+    gnm = {'type': 'animation', 'name': 'random-%d' % seed,
+           'camera': {'center': {'x': random_spline(rs, -0.2, 0.2, animated), 'y': random_spline(rs, -0.2, 0.2, animated)},
+                      'rotation': random_spline(rs, -40, 40, animated), 'scale': random_spline(rs, 0.15, 0.35, animated)},
+           'time': {'duration': 2, 'frame_width': 1.0 if animated else 0.0},
+           'palette': [[0.0] + configs.palette_encode(configs.grey_ramp())],
+           'xforms': xforms}
+    if animated:
+        ramp = configs.grey_ramp()[::-1].copy()
+        gnm['palette'].append([1.0] + configs.palette_encode(ramp))
+    if rs.rand() < 0.4:
+        gnm['final_xform'] = {'color': 0.2, 'color_speed': float(rs.uniform(0, 0.5)),
+                              'pre_affine': configs._affine(float(rs.uniform(-10, 10)), float(rs.uniform(0.9, 1.1)), 0.0, 0.0),
+                              'variations': {'linear': {'weight': 1.0}}}
+    prof = {'width': 384, 'height': 216, 'spp': 2 ** 24 / (384.0 * 216.0), 'fps': 24, 'duration': 2,
+            'frame_width': 1.0 if animated else 0.0, 'output': {'type': 'raw'},
+            'filter_order': ['bilateral', 'logscale', 'colorclip']}
+    return gnm, prof
+
+
+@pytest.mark.parametrize('seed', list(range(1, 17)))
+def test_random_genome_parity(mgr, seed):
+    lib = _lib.load()
+    gnm, prof = random_genome(seed)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    dim = mgr.fb.calc_dim(gprof.width, gprof.height)
+    tc = 0.37
+    ts, td = frame_times(gprof, tc)
+    _lib.check(lib.fl_interp(mgr.fb.ctx, g, dim.w, dim.h, ts, td))
+    dev = mgr.fb.read('params', (1024, rdr.packer.pstride), np.float32, g)
+    F = prepare(gnm, prof, tc)
+    ref = F['params']
+    names = ['.'.join(n) for n in rdr.packer.packed]
+    lastden = names.index('den.' + rdr.packer.xform_keys[-1])
+    assert np.all(dev[:, lastden] >= 1.0)
+    dev[:, lastden] = ref[:, lastden]
+    structural = np.array([n.split('.')[-1].startswith('#') or n.startswith('pad') for n in names])
+    assert np.array_equal(dev[:, structural].view(np.uint32), ref[:, structural].view(np.uint32)), 'structure words'
+    err = np.abs(dev - ref)[:, ~structural] / (np.abs(ref[:, ~structural]) + 1.0)
+    i = np.unravel_index(np.argmax(err), err.shape)
+    assert err.max() < 5e-5, (np.array(names)[~structural][i[1]], err.max())
+
+    # short iterate vs the flam3-style game on the oracle's blocks
+    n = 2 ** 24
+    run = C.c_uint64()
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(n), 64, 1, C.byref(run)))
+    nbins = dim.ah * dim.astride
+    front = mgr.fb.read('front', (nbins, 4), np.float32).astype(np.float64)
+    assert np.isfinite(front).all()
+    refh, _, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, 8)
+    refh = refh.astype(np.float64)
+    fg, fr = front[:, 3].sum() / run.value, refh[:, 3].sum() / n
+    assert abs(fg - fr) < 0.01 + 0.02 * fr, (fg, fr)
+    if fr > 0.02:
+        cg, cr = front[:, :3].sum(0) / front[:, 3].sum(), refh[:, :3].sum(0) / refh[:, 3].sum()
+        assert np.abs(cg - cr).max() < 2.5 / 255, (cg, cr)
+        H, W = dim.ah // 16 * 16, dim.astride // 16 * 16
+        def blocks(a):
+            return a[:, 3].reshape(dim.ah, dim.astride)[:H, :W].reshape(H // 16, 16, W // 16, 16).sum((1, 3))
+        bg, br = blocks(front), blocks(refh)
+        l1 = np.abs(bg / bg.sum() - br / br.sum()).sum()
+        assert l1 < 0.05, l1
