@@ -34,16 +34,18 @@ __device__ __forceinline__ int shear_idx(const fl_dim &d, float2 pat, int x, int
 }
 
 // cuburn/code/filters.py:71-77 + cuburn/code/color.py:25-40
-__global__ void __launch_bounds__(256) k_yuv_to_rgb(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ src) {
-    PIX_IDX(d);
-    float4 p = src[gi];
+__device__ __forceinline__ float4 yuv_px(float4 p) {
     float u = p.y - 0.5f * p.w, v = p.z - 0.5f * p.w;
     float4 o;
     o.x = fmaxf(0.0f, p.x + 1.402f * v);
     o.y = fmaxf(0.0f, p.x - 0.34414f * u - 0.71414f * v);
     o.z = fmaxf(0.0f, p.x + 1.772f * u);
     o.w = p.w;
-    dst[gi] = o;
+    return o;
+}
+__global__ void __launch_bounds__(256) k_yuv_to_rgb(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ src) {
+    PIX_IDX(d);
+    dst[gi] = yuv_px(src[gi]);
 }
 
 // cuburn/code/filters.py:106-117
@@ -675,20 +677,19 @@ k_den_blur2_lds(fl_dim d, float2 *__restrict__ PR, const float *__restrict__ W, 
 }
 
 // cuburn/code/filters.py:41-53
-__global__ void __launch_bounds__(256) k_logscale(fl_dim d, float4 *__restrict__ buf, float k1, float k2) {
-    PIX_IDX(d);
-    float4 p = buf[gi];
+__device__ __forceinline__ float4 logscale_px(float4 p, float k1, float k2) {
     const float ls = fmaxf(0.0f, fdiv(k1 * flog(1.0f + p.w * k2), p.w));    // NaN at w == 0 -> 0
     p.x *= ls; p.y *= ls; p.z *= ls; p.w *= ls;
-    buf[gi] = p;
+    return p;
+}
+__global__ void __launch_bounds__(256) k_logscale(fl_dim d, float4 *__restrict__ buf, float k1, float k2) {
+    PIX_IDX(d);
+    buf[gi] = logscale_px(buf[gi], k1, k2);
 }
 
 // cuburn/code/filters.py:354-412
-__global__ void __launch_bounds__(256)
-k_colorclip(fl_dim d, float4 *__restrict__ buf, float vib, float highpow, float gam, float lin, float lingam) {
-    PIX_IDX(d);
-    float4 p = buf[gi];
-    if (p.w <= 0.0f) { buf[gi] = make_float4(0, 0, 0, 0); return; }
+__device__ __forceinline__ float4 colorclip_px(float4 p, float vib, float highpow, float gam, float lin, float lingam) {
+    if (p.w <= 0.0f) return make_float4(0, 0, 0, 0);
     const float4 o = p;
     float alpha = fpow(p.w, gam);
     if (p.w < lin) {
@@ -718,7 +719,40 @@ k_colorclip(fl_dim d, float4 *__restrict__ buf, float vib, float highpow, float 
     p.y = fminf(1.0f, p.y + (1.0f - vib) * fpow(o.y, gam));
     p.z = fminf(1.0f, p.z + (1.0f - vib) * fpow(o.z, gam));
     p.w = alpha;
-    buf[gi] = p;
+    return p;
+}
+__global__ void __launch_bounds__(256)
+k_colorclip(fl_dim d, float4 *__restrict__ buf, float vib, float highpow, float gam, float lin, float lingam) {
+    PIX_IDX(d);
+    buf[gi] = colorclip_px(buf[gi], vib, highpow, gam, lin, lingam);
+}
+
+// Fused ends of the default chains (the ABI defers `yuv` and the un-normalising step of the DE
+// so that the next filter call can take them along; every pixel goes through the same device
+// functions in the same order as in the separate kernels: bit-identical results).
+//   yuv -> DE prep:  accumulator -> N, PR.x, W in one pass (saves a float4 round trip)
+__global__ void __launch_bounds__(256)
+k_yuv_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float *__restrict__ W,
+               const float4 *__restrict__ src, float dpow)
+{
+    PIX_IDX(d);
+    const float4 p = yuv_px(src[gi]);
+    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
+    N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
+    PR[gi].x = fpow(p.w, dpow);
+    W[gi] = p.w;
+}
+//   DE finish [-> logscale] [-> colorclip] in one pass
+__global__ void __launch_bounds__(256)
+k_de_finish_tone(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ N, int do_log, float k1, float k2,
+                 int do_clip, float vib, float highpow, float gam, float lin, float lingam)
+{
+    PIX_IDX(d);
+    const float4 n = N[gi];
+    float4 p = make_float4(n.x * n.w, n.y * n.w, n.z * n.w, n.w);
+    if (do_log) p = logscale_px(p, k1, k2);
+    if (do_clip) p = colorclip_px(p, vib, highpow, gam, lin, lingam);
+    dst[gi] = p;
 }
 
 // cuburn/code/filters.py:294-302
@@ -846,6 +880,10 @@ void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout
                       else launch_de_pk_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
+}
+void launch_yuv_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow) { hipLaunchKernelGGL(k_yuv_de_prep2, GRID(d), 0, st, d, N, (float2 *)PR, W, src, dpow); }
+void launch_de_finish_tone(hipStream_t st, fl_dim d, float4 *dst, const float4 *N, bool do_log, float k1, float k2, bool do_clip, const float *cc) {
+    hipLaunchKernelGGL(k_de_finish_tone, GRID(d), 0, st, d, dst, N, do_log ? 1 : 0, k1, k2, do_clip ? 1 : 0, do_clip ? cc[0] : 0.f, do_clip ? cc[1] : 0.f, do_clip ? cc[2] : 0.f, do_clip ? cc[3] : 0.f, do_clip ? cc[4] : 0.f);
 }
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2) { hipLaunchKernelGGL(k_logscale, GRID(d), 0, st, d, buf, k1, k2); }
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float hp, float gam, float lin, float lingam) { hipLaunchKernelGGL(k_colorclip, GRID(d), 0, st, d, buf, vib, hp, gam, lin, lingam); }

@@ -50,6 +50,12 @@ struct Lane {
     hipEvent_t ev_iter_done = nullptr;     // walkers + their RNG states
     hipEvent_t ev_out_done = nullptr;      // output-dither RNG states
     bool interp_rec = false, iter_rec = false, out_rec = false;
+    // deferred ends of the filter chain (see flush_pending): a `yuv` that has not run yet, and a
+    // DE result that still sits normalised in `pend_N` (+ a logscale to apply while un-normalising)
+    bool pend_yuv = false, pend_finish = false, pend_log = false;
+    const float4 *pend_N = nullptr;
+    float pend_k1 = 0.0f, pend_k2 = 0.0f;
+    fl_dim pend_dim = {0, 0, 0, 0, 0};
 };
 
 struct fl_ctx {
@@ -125,12 +131,16 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *o)
     o->astride = 32 * ((o->aw + 31) / 32);
 }
 
+static void flush_pending(fl_ctx *c);
+
 static void free_fb(fl_ctx *c)
 {
     hipFree(L(c).d_front); hipFree(L(c).d_back); hipFree(L(c).d_side); hipFree(L(c).d_blur);
     hipFree(L(c).d_atom); hipFree(L(c).d_hot); hipFree(L(c).d_outpix);
     L(c).d_front = L(c).d_back = L(c).d_side = nullptr; L(c).d_blur = nullptr; L(c).d_atom = nullptr;
     L(c).d_hot = nullptr; L(c).d_outpix = nullptr; L(c).nbins = 0; L(c).outpix_bytes = 0;
+    L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = false;      // whatever was deferred dies with the buffers
+    L(c).pend_N = nullptr;
 }
 
 // cuburn/render.py:121-161 Framebuffers.alloc / set_dim: grow-only; on OOM free everything
@@ -472,6 +482,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
+    flush_pending(c);
     if ((rc = wait_other(c, 1))) return rc;                 // walkers / RNG states are shared between lanes
     if ((rc = do_clear(c, d, true))) return rc;
     const uint32_t nt = (uint32_t)c->nw * 64;
@@ -507,6 +518,27 @@ static void gauss7(float stdev, float *c)      // cuburn/filters.py:11-16
     for (int i = 0; i < 7; ++i) c[i] /= s;
 }
 
+// The filter entry point defers two cheap per-pixel steps so that the NEXT call can take them
+// along in one pass (cuburn's default chains are yuv -> bilateral -> logscale -> colorclip /
+// smearclip): `yuv` directly in front of `bilateral` becomes part of the DE's preparation pass,
+// and the DE's final un-normalising pass takes a following `logscale` and `colorclip` with it.
+// Anything else that looks at the buffers (another filter, output, the debug taps, the next
+// frame) first runs what is pending, so the observable behaviour is that of the separate kernels
+// (the fused kernels run the same per-pixel device functions in the same order).
+static void flush_pending(fl_ctx *c)
+{
+    Lane &ln = L(c);
+    if (ln.pend_yuv) {
+        launch_yuv_to_rgb(ln.stream, ln.pend_dim, ln.d_back, ln.d_front);
+        std::swap(ln.d_front, ln.d_back);
+        ln.pend_yuv = false;
+    }
+    if (ln.pend_finish) {
+        launch_de_finish_tone(ln.stream, ln.pend_dim, ln.d_front, ln.pend_N, ln.pend_log, ln.pend_k1, ln.pend_k2, false, nullptr);
+        ln.pend_finish = ln.pend_log = false;
+    }
+}
+
 int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_t np)
 {
     REQUIRE(c, "null ctx");
@@ -519,12 +551,13 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     EvPair *e = ev_begin(c, c->filt_ev);
     switch (id) {
     case FL_FILT_YUV:
-        launch_yuv_to_rgb(st, d, L(c).d_back, L(c).d_front);
-        std::swap(L(c).d_front, L(c).d_back);
+        flush_pending(c);
+        L(c).pend_yuv = true; L(c).pend_dim = d;             // runs with the next call
         break;
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
+        if (L(c).pend_finish || getenv("FLAME_DE_REFERENCE_FORM") || getenv("FLAME_DE_GATHER")) flush_pending(c);
         if (getenv("FLAME_DE_REFERENCE_FORM")) {         // the literal per-tap form of the reference kernel
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur(st, d, L(c).d_blur, L(c).d_front, pat, 0, k7);
@@ -540,13 +573,16 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             float *PRa = (float *)L(c).d_side, *PRb = PRa + 2 * nb2;
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
             // density plane W: written by the prep / bilateral passes, read by the next blur pass
-            launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
+            if (L(c).pend_yuv) { launch_yuv_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]); L(c).pend_yuv = false; }
+            else launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur2_lds(st, d, pat, PRa, L(c).d_blur, k7);
                 launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb); std::swap(PRa, PRb);
             }
-            launch_de_finish(st, d, L(c).d_front, Na);
+            // 8 swaps: the result sits normalised in Na == d_back; un-normalising it into d_front
+            // is left pending so that a logscale / colorclip that follows can ride along
+            L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
             break;
         }
         // planes carved from the float4 side buffer: RA = 1/(avg+1e-6), Pa / Pb = w^dpow ping-pong
@@ -565,13 +601,22 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     } break;
     case FL_FILT_LOGSCALE:
         REQUIRE(np >= 2, "logscale needs k1,k2");
+        if (L(c).pend_finish && !L(c).pend_log && !L(c).pend_yuv) { L(c).pend_log = true; L(c).pend_k1 = p[0]; L(c).pend_k2 = p[1]; break; }
+        flush_pending(c);
         launch_logscale(st, d, L(c).d_front, p[0], p[1]);
         break;
     case FL_FILT_COLORCLIP:
         REQUIRE(np >= 5, "colorclip needs vib,highpow,gam,lin,lingam");
+        if (L(c).pend_finish && !L(c).pend_yuv) {
+            launch_de_finish_tone(st, d, L(c).d_front, L(c).pend_N, L(c).pend_log, L(c).pend_k1, L(c).pend_k2, true, p);
+            L(c).pend_finish = L(c).pend_log = false;
+            break;
+        }
+        flush_pending(c);
         launch_colorclip(st, d, L(c).d_front, p[0], p[1], p[2], p[3], p[4]);
         break;
     case FL_FILT_SMEARCLIP:              // cuburn/filters.py:142-163
+        flush_pending(c);
         REQUIRE(np >= 4, "smearclip needs width,gam_m_1,lin,lingam");
         gauss7(p[0], k7);
         launch_gamma_full_hi(st, d, L(c).d_side, L(c).d_front);
@@ -582,6 +627,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         launch_smearclip(st, d, L(c).d_front, L(c).d_side, p[1], p[2], p[3]);
         break;
     case FL_FILT_HALOCLIP:               // cuburn/filters.py:113-130
+        flush_pending(c);
         REQUIRE(np >= 1, "haloclip needs gam_m_1");
         gauss7(1.0f, k7);
         launch_apply_gamma(st, d, L(c).d_blur, L(c).d_front, 0.1f);
@@ -590,10 +636,12 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         launch_haloclip(st, d, L(c).d_front, L(c).d_blur, p[0]);
         break;
     case FL_FILT_PLAINCLIP:
+        flush_pending(c);
         REQUIRE(np >= 4, "plainclip needs gam_m_1,lin,lingam,brightness");
         launch_plainclip(st, d, L(c).d_front, p[0], p[1], p[2], p[3]);
         break;
     case FL_FILT_LOGENCODE:
+        flush_pending(c);
         REQUIRE(np >= 1, "logencode needs degamma");
         launch_logencode(st, d, L(c).d_back, L(c).d_front, p[0]);
         std::swap(L(c).d_front, L(c).d_back);
@@ -613,6 +661,7 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
+    flush_pending(c);                                       // deferred ends of the filter chain
     void *dst = dev_out ? (void *)(uintptr_t)dev_out : L(c).d_outpix;
     { int rc2 = wait_other(c, 2); if (rc2) return rc2; }   // the dither RNG states are shared between lanes
     fl_mwc *rng_out = c->d_rng + (size_t)c->nslots * c->nw * 64 + FL_PAL_H * 256;
@@ -701,6 +750,8 @@ static int buf_ptr(fl_ctx *c, fl_genome *g, int which, void **p, size_t *cap)
 int fl_read_buffer(fl_ctx *c, fl_genome *g, int which, void *dst, size_t nbytes)
 {
     REQUIRE(c && dst, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    flush_pending(c);
     void *p; size_t cap;
     int rc = buf_ptr(c, g, which, &p, &cap);
     if (rc) return rc;
@@ -713,6 +764,8 @@ int fl_read_buffer(fl_ctx *c, fl_genome *g, int which, void *dst, size_t nbytes)
 int fl_buffer_ptr(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size_t *nbytes)
 {
     REQUIRE(c && dev_ptr && nbytes, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    flush_pending(c);
     int rc = buf_ptr(c, g, which, dev_ptr, nbytes);
     if (rc) return rc;
     sync_all(c);
@@ -722,6 +775,8 @@ int fl_buffer_ptr(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size_t *nb
 int fl_write_buffer(fl_ctx *c, fl_genome *g, int which, const void *src, size_t nbytes)
 {
     REQUIRE(c && src, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    flush_pending(c);
     void *p; size_t cap;
     int rc = buf_ptr(c, g, which, &p, &cap);
     if (rc) return rc;
@@ -738,6 +793,7 @@ int fl_debug_clear(fl_ctx *c, uint32_t w, uint32_t h, int reset_points)
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
+    flush_pending(c);
     return do_clear(c, d, reset_points != 0);
 }
 
@@ -760,6 +816,7 @@ int fl_debug_flush(fl_ctx *c, uint32_t w, uint32_t h)
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
     if (rc) return rc;
+    flush_pending(c);
     return do_flush(c, d);
 }
 

@@ -734,3 +734,31 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     assert err.max() < 2e-2 and err.mean() < 2e-4, (err.max(), err.mean())
     assert np.percentile(err, 99.9) < 2e-3, np.percentile(err, 99.9)
     m.fb.free()
+
+
+def test_deferred_filter_fusion_is_bit_identical(mgr):
+    """fl_filter defers `yuv` and the DE's un-normalising pass so that bilateral / logscale /
+    colorclip can take them along in one kernel.  Looking at the buffer between the calls forces
+    every step to run on its own: both ways must give the same bits, for every chain shape."""
+    lib = _lib.load()
+    dim = mgr.fb.calc_dim(FW, FH)
+    buf = synth_accum(dim)
+    steps = {'yuv': [], 'bilateral': [6.0 * FW / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
+             'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)], 'smearclip': [0.7, 0.25 - 1, 0.01, 0.01 ** (0.25 - 1)]}
+
+    def run(chain, peek):
+        _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 0))
+        mgr.fb.write('front', buf)
+        for name in chain:
+            arr = np.asarray(steps[name], np.float32)
+            _lib.check(lib.fl_filter(mgr.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
+            if peek:
+                mgr.fb.read('front', buf.shape, np.float32)
+        return mgr.fb.read('front', buf.shape, np.float32)
+
+    for chain in (['yuv', 'bilateral', 'logscale', 'colorclip'], ['yuv', 'bilateral', 'logscale', 'smearclip'],
+                  ['yuv', 'bilateral'], ['bilateral', 'colorclip'], ['yuv', 'logscale', 'colorclip'],
+                  ['yuv', 'bilateral', 'bilateral', 'logscale'], ['yuv', 'yuv'], ['bilateral', 'logscale', 'logscale', 'colorclip']):
+        a, b = run(chain, False), run(chain, True)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), chain
+        assert np.isfinite(a).all()
