@@ -162,17 +162,26 @@ def main():
     # context with ONE stream lane renders a few frames, its HIP-event kernel times are what
     # rocprofv3 --kernel-trace reports for the same command line with FLAME_LANES=1
     # (profiles/).  `value` above comes from the real two-lane pipeline.
-    ksteps = max(2, min(args.steps, 4))
+    ksteps = max(4, min(args.steps, 16))
     os.environ['FLAME_LANES'] = '1'
     kmgr = render.RenderManager(device=local, nslots=nslots, host_seed=1042 + rank)
     del os.environ['FLAME_LANES']
     kmgr.accum_mode, kmgr.fuse = mgr.accum_mode, mgr.fuse
     krdr = render.Renderer(gnm, gprof)
-    for k in range(ksteps + 1):
-        if k == 1:
+    # frames are queued back to back (one lane: nothing overlaps, but the GPU never idles between
+    # kernels, as in the rocprofv3 runs): a frame-by-frame loop lets the clocks sag between frames
+    prev = None
+    for k in range(ksteps + 2):
+        if k == 2:
+            if prev is not None:
+                prev.synchronize()
+                prev = None
             kmgr.timings_reset()
         e, _ = kmgr.queue_frame(krdr, gnm, gprof, tc)
-        e.synchronize()
+        if prev is not None:
+            prev.synchronize()
+        prev = e
+    prev.synchronize()
     acc = kmgr.timings()
     acc['samples'] = kmgr.last_nsamples * ksteps
     acc['steps'] = ksteps

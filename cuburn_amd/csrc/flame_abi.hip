@@ -115,6 +115,18 @@ static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
     hipEventRecord(p.a, L(c).stream);
     return &c->pool[c->pool_used - 1];
 }
+// a pair whose events are recorded by the kernel launch itself (hipExtLaunchKernelGGL)
+static EvPair *ev_pair(fl_ctx *c, std::vector<EvPair> &list)
+{
+    if (!c->timing) return nullptr;
+    if (c->pool_used == c->pool.size()) {
+        EvPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        c->pool.push_back(p);
+    }
+    list.push_back(c->pool[c->pool_used++]);
+    return &c->pool[c->pool_used - 1];
+}
 static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, L(c).stream); }
 
 #pragma GCC visibility push(default)
@@ -443,11 +455,11 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         int rc = ensure_binned(c, d, nrounds - fuse, &tiles_x, &nbins, &nbatch_total, &wide);
         if (rc) return rc;
     }
-    EvPair *e = ev_begin(c, c->iter_ev);
+    EvPair *e = ev_pair(c, c->iter_ev);
     launch_iter(L(c).stream, c->nw, count, acc == FL_ACCUM_BINNED && wide ? 3 : acc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
-                tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir);
-    ev_end(c, e);
+                tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir,
+                e ? e->a : nullptr, e ? e->b : nullptr);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {

@@ -13,6 +13,7 @@
 //     value is examined one round later (latency hidden) to drain nearly-full cells.
 #include "variations.h"
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 template <int NW>
 __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_t phase) {
@@ -400,14 +401,15 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
                  uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                  uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
-                 uint32_t *log, uint32_t *dir)
+                 uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total};
     const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins);
 #define LAUNCH(NW, C, A) do { \
         static bool attr_done = false; \
         if (!attr_done) { hipFuncSetAttribute((const void *)k_iter<NW, C, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
-        hipLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, prog, params, palette, \
+        /* the timing events bracket the kernel itself (recorded by the dispatch packet), not the launch call */ \
+        hipExtLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, ev_start, ev_stop, 0, prog, params, palette, \
         rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg, log, dir); } while (0)
     if (acc == 2) { if (nw == 4) LAUNCH(4, false, 2); else LAUNCH(8, false, 2); }
     else if (acc == 1) {

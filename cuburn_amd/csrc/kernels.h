@@ -12,7 +12,8 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
                  uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                  uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
-                 uint32_t *log, uint32_t *dir);
+                 uint32_t *log, uint32_t *dir,
+                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot);
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
 void launch_apply_xf_tap(hipStream_t st, const int32_t *prog, const float *params, uint32_t ts, int xfi,
