@@ -437,8 +437,33 @@ k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRo
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef f2 f2u __attribute__((aligned(4)));
 __device__ __forceinline__ f2 f2fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// Sheared tiles.  A rectangular tile needs a halo of 16 pixels in x AND y for a diagonal
+// direction (64x48 staged pixels for 32x16 outputs: 77 KB, two workgroups per CU).  Here row j of
+// a tile (and of its halo) starts S(j) = floor(j * K / 2) pixels further right, K/2 being the
+// direction's x step per row (K = 2, -2 for the diagonals, 4 / -4 for slopes +-1/2 along x,
+// -1 / 1 for slopes -+1/2 along y, 0 for the axes): a tap then lands in (almost) the same column
+// of the staged parallelogram, whose width is 32 + 2 * margin with margin 0 or 1 instead of 16.
+// For odd K the residual column offset of a tap depends on the parity p of the output row:
+// coff(r, p) = coff(r, 0) + p * delta(r), delta in {-1, 0, 1} — three base addresses.
+template <int P> __host__ __device__ __forceinline__ constexpr int de_shear_k() {
+    constexpr int k[8] = {0, 0, 2, -2, 4, -1, -4, 1};
+    return k[P];
+}
+template <int P> __host__ __device__ __forceinline__ constexpr int de_shear(int j) { return (j * de_shear_k<P>()) >> 1; }
+template <int P> __host__ __device__ __forceinline__ constexpr int de_coff(int r, int p) {
+    return tap_dx<P>(r) - (de_shear<P>(p + tap_dy<P>(r)) - de_shear<P>(p));
+}
+template <int P> __host__ __device__ __forceinline__ constexpr int de_margin() {
+    int m = 0;
+    for (int r = -16; r <= 16; ++r) for (int p = 0; p < 2; ++p) { int v = de_coff<P>(r, p); v = v < 0 ? -v : v; m = v > m ? v : m; }
+    return m;
+}
+template <int P> __host__ __device__ __forceinline__ constexpr int de_span() {        // |S(15)|: extra width of a band of tiles
+    int v = de_shear<P>(DE_TH - 1);
+    return v < 0 ? -v : v;
+}
 template <int PATTERN> __host__ __device__ __forceinline__ constexpr int de_pk_row_stride() {
-    int rs = 6 * (DE_TW + 2 * de_hx<PATTERN>());
+    int rs = 6 * (DE_TW + 2 * de_margin<PATTERN>());
     while (rs % 64 != 16) ++rs;
     return rs;
 }
@@ -449,14 +474,16 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
                   const float4 *__restrict__ N, const float2 *__restrict__ PR,
                   float sstd, float cstd, float dstd, float dpow, float gspeed)
 {
-    constexpr int HX = de_hx<PATTERN>(), HY = de_hy<PATTERN>();
-    constexpr int LW = DE_TW + 2 * HX, LH = DE_TH + 2 * HY;
+    constexpr int HY = de_hy<PATTERN>(), K = de_shear_k<PATTERN>(), M = de_margin<PATTERN>();
+    constexpr int LW = DE_TW + 2 * M, LH = DE_TH + 2 * HY;
     constexpr int RS = de_pk_row_stride<PATTERN>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *pl = reinterpret_cast<float *>(smem);                         // [LH][6][LW] (+ row padding)
 
     const int tid = threadIdx.x;
-    const int bx0 = blockIdx.x * DE_TW, by0 = blockIdx.y * DE_TH;
+    // x of column 0 of tile row 0; for K > 0 the band starts S(15) to the left so that its last row reaches x = 0
+    const int bx0 = (int)blockIdx.x * DE_TW - (K > 0 ? de_shear<PATTERN>(DE_TH - 1) : 0);
+    const int by0 = blockIdx.y * DE_TH;
     constexpr int NIT = (LH * LW + 255) / 256;
     float4 tn[NIT];
     float2 tp[NIT];
@@ -464,7 +491,7 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
     for (int it = 0; it < NIT; ++it) {
         const int idx = min(it * 256 + tid, LH * LW - 1);
         const int ly = idx / LW, lx = idx - ly * LW;
-        const int gx = min(max(bx0 + lx - HX, 0), (int)d.astride - 1);
+        const int gx = min(max(bx0 + (((ly - HY) * K) >> 1) - M + lx, 0), (int)d.astride - 1);
         const int gy = min(max(by0 + ly - HY, 0), (int)d.ah - 1);
         const uint32_t g = (uint32_t)(gy * (int)d.astride + gx);
         tn[it] = N[g];
@@ -491,18 +518,24 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
         spk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fexp(fdiv(df * df, -FM_SQRT2 * sstd)))));
     }
 
-    const int ox = tid & 15, oy = tid >> 4;                  // pixels (ox, oy) and (ox + 16, oy)
-    // byte address of the centre of pixel A in plane 0 (dynamic LDS starts at the kernel's LDS base)
-    uint32_t ctr = (uint32_t)(size_t)pl + (uint32_t)(((oy + HY) * RS + ox + HX) * 4);
+    const int ox = tid & 15, oy = tid >> 4;                  // pixels (ox, oy) and (ox + 16, oy) of the sheared tile
+    const int par = (K & 1) ? (oy & 1) : 0;                  // row parity: only matters for odd K
+    // byte address of the centre of pixel A in plane 0 (dynamic LDS starts at the kernel's LDS base),
+    // and the same shifted by one column either way for rows of odd parity
+    uint32_t ctr = (uint32_t)(size_t)pl + (uint32_t)(((oy + HY) * RS + ox + M) * 4);
+    uint32_t ctrp = ctr + 4u * (uint32_t)par, ctrm = ctr - 4u * (uint32_t)par;
 
     // One ds_read2_b32 brings the pair (plane[p], plane[p + 16]) into an aligned register pair.
     // The compiler's own pairing of LDS reads follows program order, not this pixel pairing, so
     // the reads are written out; they complete asynchronously and are waited for by the
     // "s_waitcnt lgkmcnt(0)" at the top of the step that consumes them (see STEP below).
 #define RD2(dst, addr, o0) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"((o0) + 16) : "memory")
+#define DELTA(r) (de_coff<PATTERN>(r, 1) - de_coff<PATTERN>(r, 0))
+#define BASE(r) (DELTA(r) == 0 ? ctr : DELTA(r) > 0 ? ctrp : ctrm)
+#define TAPOFF(r) (tap_dy<PATTERN>(r) * RS + de_coff<PATTERN>(r, 0))
     // pairs needed before the loop, read the ordinary way
-    const float *c0 = pl + (oy + HY) * RS + ox + HX;
-#define CPAIR(k, r) ((f2){c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r)], c0[tap_dy<PATTERN>(r) * RS + (k) * LW + tap_dx<PATTERN>(r) + 16]})
+    const float *c0 = pl + (oy + HY) * RS + ox + M;
+#define CPAIR(k, r) ((f2){c0[TAPOFF(r) + par * DELTA(r) + (k) * LW], c0[TAPOFF(r) + par * DELTA(r) + (k) * LW + 16]})
     const f2 cw = CPAIR(3, 0);
     const f2 cfix = cw * (f2){frcp(cw.x + 1.0e-6f), frcp(cw.y + 1.0e-6f)};
     const f2 cx = CPAIR(0, 0) * cfix, cy = CPAIR(1, 0) * cfix, cz = CPAIR(2, 0) * cfix;
@@ -521,8 +554,8 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
         constexpr int g = decltype(gc)::value;
 #define ISSUE_TAP(k) if constexpr (-15 + g * 2 + (k) <= 15) { \
             constexpr int r = -15 + g * 2 + (k); \
-            const uint32_t an = ctr + (uint32_t)((tap_dy<PATTERN>(r + 1) * RS + tap_dx<PATTERN>(r + 1)) * 4); \
-            const uint32_t ap = ctr + (uint32_t)((tap_dy<PATTERN>(r) * RS + tap_dx<PATTERN>(r) + 4 * LW) * 4); \
+            const uint32_t an = BASE(r + 1) + (uint32_t)(TAPOFF(r + 1) * 4); \
+            const uint32_t ap = BASE(r) + (uint32_t)((TAPOFF(r) + 4 * LW) * 4); \
             RD2(L[g & 1][k][0], an, 0); RD2(L[g & 1][k][1], an, LW); RD2(L[g & 1][k][2], an, 2 * LW); RD2(L[g & 1][k][3], an, 3 * LW); \
             RD2(L[g & 1][k][4], ap, 0); RD2(L[g & 1][k][5], ap, LW); }
         ISSUE_TAP(0) ISSUE_TAP(1)
@@ -534,7 +567,7 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(T[0][0]), "+v"(T[0][1]), "+v"(T[0][2]), "+v"(T[0][3]), "+v"(T[0][4]), "+v"(T[0][5]),
                        "+v"(T[1][0]), "+v"(T[1][1]), "+v"(T[1][2]), "+v"(T[1][3]), "+v"(T[1][4]), "+v"(T[1][5]),
-                       "+v"(ctr), "+v"(wsum), "+v"(outx), "+v"(outy), "+v"(outz), "+v"(outw));
+                       "+v"(ctr), "+v"(ctrp), "+v"(ctrm), "+v"(wsum), "+v"(outx), "+v"(outy), "+v"(outz), "+v"(outw));
         if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
         asm volatile("" : "+v"(px), "+v"(pw));      // the arithmetic below starts after the reads above are issued
 #pragma unroll
@@ -565,13 +598,19 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
         (step(std::integral_constant<int, G>{}), ...);
     }(std::make_integer_sequence<int, 16>{});
 #undef RD2
+#undef DELTA
+#undef BASE
+#undef TAPOFF
+    const int xA = bx0 + ((oy * K) >> 1) + ox;               // image column of pixel A
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float ow = h ? outw.y : outw.x, ws = h ? wsum.y : wsum.x;
         const float sx = h ? outx.y : outx.x, sy = h ? outy.y : outy.x, sz = h ? outz.y : outz.x;
         const float wn = ow * frcp(ws + 1e-10f);
         const float rn = ow >= 1.17549435e-38f ? frcp(ow) : 0.0f;       // v_rcp_f32 of a denormal is +inf
-        const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox + 16 * h);
+        const int xo = xA + 16 * h;
+        if (xo < 0 || xo >= (int)d.astride) continue;        // the parallelogram sticks out of the image at both ends of a band
+        const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + xo);
         Nout[go] = make_float4(sx * rn, sy * rn, sz * rn, wn);
         PRout[go].x = fpow(wn, dpow);
         Wout[go] = wn;
@@ -860,8 +899,8 @@ static void launch_de_pk_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRo
     const size_t lds = (size_t)LH * de_pk_row_stride<P>() * 4;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void *)k_de_bilateral_pk<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_de_bilateral_pk<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, Wout, N, PR,
-                       sstd, cstd, dstd, dpow, gspeed);
+    hipLaunchKernelGGL(k_de_bilateral_pk<P>, dim3((d.astride + de_span<P>() + DE_TW - 1) / DE_TW, d.ah / DE_TH), dim3(256), lds, st,
+                       d, Nout, PRout, Wout, N, PR, sstd, cstd, dstd, dpow, gspeed);
 }
 template <int P>
 static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
