@@ -148,9 +148,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Preheat is timed per rank, so it must not contain collectives (ranks would run different
+    # numbers of them and deadlock): plain local frames, no gather / all-reduce.
     t_heat = time.perf_counter()
     while time.perf_counter() - t_heat < args.preheat_seconds:
-        run(4)
+        pend = None
+        for _ in range(4):
+            nxt = mgr.queue_frame(rdr, gnm, gprof, tc)
+            if pend is not None:
+                pend[0].synchronize()
+            pend = nxt
+        pend[0].synchronize()
+    fence()
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
