@@ -102,9 +102,13 @@ static const int kKnownVars[] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,
     34,35,36,37,38,39,40,41,42,43,44,45,46,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,66,67,68,69,70,71,72,73,
     74,75,76,77,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95,97,98};
 
+// Kernel timing keeps one event pair per launch since the last fl_timings_reset(); a long render
+// that never asks for timings stops recording after kMaxTimed launches instead of growing forever.
+static const size_t kMaxTimed = 8192;
+
 static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
 {
-    if (!c->timing) return nullptr;
+    if (!c->timing || c->pool_used >= kMaxTimed) return nullptr;
     if (c->pool_used == c->pool.size()) {
         EvPair p;
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
@@ -118,7 +122,7 @@ static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
 // a pair whose events are recorded by the kernel launch itself (hipExtLaunchKernelGGL)
 static EvPair *ev_pair(fl_ctx *c, std::vector<EvPair> &list)
 {
-    if (!c->timing) return nullptr;
+    if (!c->timing || c->pool_used >= kMaxTimed) return nullptr;
     if (c->pool_used == c->pool.size()) {
         EvPair p;
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;

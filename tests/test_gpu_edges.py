@@ -200,3 +200,27 @@ def test_walker_geometry_follows_image_size():
     evt, _ = p.queue_frame(render.Renderer(gnm, big), gnm, big, 0.5); evt.synchronize()
     assert (p.fb.nw, p.fb.nslots) == (4, NSLOTS)
     m.fb.free(); p.fb.free()
+
+
+def test_long_run_without_timing_queries(mgr):
+    """A long render that never asks for kernel timings: the per-launch timing events are capped
+    (8192 pairs since the last reset), rendering goes on, and a reset re-arms the timers."""
+    gnm, prof = nxf_flame(3, 64, 64)
+    prof = dict(prof, spp=40.0)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    mgr.timings_reset()
+    last = None
+    for k in range(1400):                       # ~7 timed launches per frame
+        evt, out = mgr.queue_frame(rdr, gnm, gprof, 0.5)
+        if last is not None:
+            last.synchronize()
+        last = evt
+    last.synchronize()
+    assert np.array(out)[..., 3].max() > 0
+    t = mgr.timings()
+    assert 0 < t['launches'] <= 8192 and t['iter_ms'] > 0
+    mgr.timings_reset()
+    evt, out = mgr.queue_frame(rdr, gnm, gprof, 0.5); evt.synchronize()
+    t = mgr.timings()
+    assert t['launches'] == 1 and t['iter_ms'] > 0 and t['filter_ms'] > 0
