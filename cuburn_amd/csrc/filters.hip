@@ -629,18 +629,6 @@ k_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float *__r
     W[gi] = p.w;
 }
 
-// second density blur writing 1/(avg + 1e-6) into the .y lane of the packed plane
-__global__ void __launch_bounds__(256)
-k_den_blur_1c_rcp2(fl_dim d, float2 *__restrict__ PR, const float *__restrict__ src, int pattern, int upsample, Coefs7 k) {
-    PIX_IDX(d);
-    const float2 pat = shear_patterns[pattern];
-    float den = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-        den += src[shear_idx(d, pat, xi, yi, (float)((i - 3) * (1 << upsample)))] * k.c[i];
-    PR[gi].y = frcp(den + 1.0e-6f);
-}
-
 // Both density blurs of one direction in one pass (cuburn/code/filters.py:106-131 as driven by
 // cuburn/filters.py:80-84: 7 taps at step 1, then 7 taps at step 2 on the result), writing
 // 1/(avg + 1e-6) into PR.y.  A workgroup stages the density tile plus both halos in LDS
@@ -891,7 +879,6 @@ void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, cons
     switch (pattern) { DB(0); DB(1); DB(2); DB(3); DB(4); DB(5); DB(6); DB(7); default: break; }
 #undef DB
 }
-void launch_den_blur_1c_rcp2(hipStream_t st, fl_dim d, float *PR, const float *src, int p, int up, const float *c) { hipLaunchKernelGGL(k_den_blur_1c_rcp2, GRID(d), 0, st, d, (float2 *)PR, src, p, up, mk(c)); }
 template <int P>
 static void launch_de_pk_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
                              float sstd, float cstd, float dstd, float dpow, float gspeed) {

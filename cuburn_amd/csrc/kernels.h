@@ -48,7 +48,6 @@ void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, c
 void launch_yuv_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
 void launch_de_finish_tone(hipStream_t st, fl_dim d, float4 *dst, const float4 *N, bool do_log, float k1, float k2, bool do_clip, const float *cc5);
 void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *coefs7);
-void launch_den_blur_1c_rcp2(hipStream_t st, fl_dim d, float *PR, const float *src, int pattern, int upsample, const float *coefs7);
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
                              float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
