@@ -85,7 +85,14 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const uint32_t b_hi = (uint32_t)((u64)nbatch_total * (part + 1) / nparts);
     const uint32_t *drow = dir + (size_t)bin * nbatch_total;
 
-    for (uint32_t g0 = b_lo + wv * 64; g0 < b_hi; g0 += nwaves * 64) {
+    // palette row of a batch = its slot * 64 / nslots (iter.hip); slots_per_row = nslots / 64 >= 16
+    const uint32_t spr = nslots / FL_PAL_H;
+    const float inv_spr = 1.0f / (float)spr;
+    for (uint32_t g0v = b_lo + wv * 64; g0v < b_hi; g0v += nwaves * 64) {
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0v);      // wave-uniform
+        // batch id = batch_in_slot * nslots + slot: slot of the group's first batch, its row and the
+        // remainder, once per group (scalar); a lane's run r < 64 then adds (rem0 + r) / spr <= 4 rows
+        const uint32_t s0 = g0 % nslots, row0 = s0 / spr, rem0 = s0 - row0 * spr;
         // 64 directory entries per wave; their runs form one virtual array of `total` records
         const uint32_t batch = g0 + lane;
         const uint32_t e = batch < b_hi ? drow[batch] : 0u;
@@ -118,7 +125,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
                 rec[k] = live[k] ? log[(size_t)rbatch * batch_records + (uint32_t)((int)v + delta)] : 0u;
-                row[k] = ((rbatch % nslots) % FL_NTEMPORAL) >> 4;
+                const uint32_t rr = row0 + (uint32_t)(((float)(rem0 + r) + 0.5f) * inv_spr);
+                row[k] = rr >= FL_PAL_H ? rr - FL_PAL_H : rr;                    // the group may wrap past the last slot
             }
             u64 val[ACC_ILP];
 #pragma unroll
@@ -166,14 +174,14 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
                         uint32_t astride, uint32_t aheight, bool wide)
 {
     if (wide) {
-        static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static unsigned long long attr = 0;
+        ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, attr);
         hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024), (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4, st,
                            log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
         return;
     }
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void *)k_accum_tiles<7u>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static unsigned long long attr = 0;
+    ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
     hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8 + 1024 * 4, st, log, dir, palette, atom, out4,
                        tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
 }

@@ -884,8 +884,8 @@ static void launch_de_pk_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRo
                              float sstd, float cstd, float dstd, float dpow, float gspeed) {
     constexpr int LH = DE_TH + 2 * de_hy<P>();
     const size_t lds = (size_t)LH * de_pk_row_stride<P>() * 4;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void *)k_de_bilateral_pk<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static unsigned long long attr = 0;
+    ensure_max_dynamic_lds((const void *)k_de_bilateral_pk<P>, attr);
     hipLaunchKernelGGL(k_de_bilateral_pk<P>, dim3((d.astride + de_span<P>() + DE_TW - 1) / DE_TW, d.ah / DE_TH), dim3(256), lds, st,
                        d, Nout, PRout, Wout, N, PR, sstd, cstd, dstd, dpow, gspeed);
 }
@@ -894,14 +894,14 @@ static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PR
                               float sstd, float cstd, float dstd, float dpow, float gspeed) {
     constexpr int LW = DE_TW + 2 * de_hx<P>(), LH = DE_TH + 2 * de_hy<P>();
     const size_t lds = (size_t)LW * LH * 24 + 64 + 33 * 4 + 12;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void *)k_de_bilateral_lds<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static unsigned long long attr = 0;
+    ensure_max_dynamic_lds((const void *)k_de_bilateral_lds<P>, attr);
     hipLaunchKernelGGL(k_de_bilateral_lds<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, Wout, N, PR,
                        sstd, cstd, dstd, dpow, gspeed);
 }
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
-                             float sstd, float cstd, float dstd, float dpow, float gspeed) {
-    const bool pk = getenv("FLAME_DE_LDS_AOS") == nullptr;      // default: packed-math form; FLAME_DE_LDS_AOS=1: scalar-math form
+                             float sstd, float cstd, float dstd, float dpow, float gspeed, bool pk) {
+    // pk: packed-math form (default); otherwise the scalar-math form (FLAME_DE_LDS_AOS=1 when the context was created)
 #define DE(P) case P: if (!pk) launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); \
                       else launch_de_pk_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }

@@ -43,7 +43,8 @@ struct Lane {
     size_t outpix_bytes = 0;
     uint32_t *d_log = nullptr, *d_dir = nullptr;      // binned accumulate: sample log + directory
     size_t log_words = 0, dir_words = 0;
-    float *d_params = nullptr;        // [FL_NTEMPORAL * FL_MAX_PSTRIDE]
+    float *d_params = nullptr;        // [nslots * pstride] one block per temporal sample = per walker slot (grow-only)
+    size_t params_floats = 0;
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
     // cross-lane ordering of the state both lanes share
     hipEvent_t ev_interp_done = nullptr;   // genome staging buffers + palette RNG states
@@ -74,9 +75,11 @@ struct fl_ctx {
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
     uint32_t frame_lane[kFrames] = {};
     uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
-    std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev;
+    std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev, de_ev;
     size_t pool_used = 0;
     bool timing = true;
+    // environment switches, read once when the context is created
+    bool env_bin_wide = false, env_de_reference = false, env_de_gather = false, env_de_aos = false;
 };
 #define L(c) ((c)->lanes[(c)->cur])
 #define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
@@ -180,6 +183,8 @@ static int ensure_fb(fl_ctx *c, const fl_dim &d)
     return FL_OK;
 }
 
+static bool env_on(const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; }
+
 int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out)
 {
     REQUIRE(out && seeds, "null argument");
@@ -192,42 +197,59 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(FL_E_NODEV, "device is not gfx950 (kernels are built for MI355X only)", __FILE__, __LINE__);
-    fl_ctx *c = new fl_ctx;
-    c->device = device;
-    if (const char *e = getenv("FLAME_LANES")) c->nlanes = atoi(e) == 1 ? 1 : 2;
-    if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
-    else {
-        for (int i = 0; i < c->nlanes; ++i) HIPCHK(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
-    c->nslots = nslots;
     // waves per iterate workgroup (4 or 8) follow from the size of the seed table
+    int nw = 0;
     {
         const uint32_t fixed = FL_PAL_H * 256 + FL_NOUT;
         const uint32_t per_wave = nslots * 64u;
-        if (nseeds == fixed + 8u * per_wave) c->nw = 8;
-        else if (nseeds != fixed + 4u * per_wave) { delete c; return fail(FL_E_INVAL, "nseeds must be nslots*64*NW + 64*256 + 65536 with NW = 4 or 8", __FILE__, __LINE__); }
+        if (nseeds == fixed + 8u * per_wave) nw = 8;
+        else if (nseeds == fixed + 4u * per_wave) nw = 4;
+        else return fail(FL_E_INVAL, "nseeds must be nslots*64*NW + 64*256 + 65536 with NW = 4 or 8", __FILE__, __LINE__);
     }
+    fl_ctx *c = new fl_ctx;
+    c->device = device;
+    c->nw = nw;
+    c->nslots = nslots;
+    c->nwalkers = nslots * (uint32_t)nw * 64 + FL_PAL_H * 256 + FL_NOUT;
+    if (const char *e = getenv("FLAME_LANES")) c->nlanes = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
-    c->nwalkers = nslots * (uint32_t)c->nw * 64 + FL_PAL_H * 256 + FL_NOUT;
-    HIPCHK(hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers));
-    HIPCHK(hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * c->nw * 64));
-    HIPCHK(hipMalloc(&c->d_counters, 8 * 4));
-    for (int i = 0; i < c->nlanes; ++i) {
-        Lane &ln = c->lanes[i];
-        HIPCHK(hipMalloc(&ln.d_params, sizeof(float) * FL_NTEMPORAL * FL_MAX_PSTRIDE));
-        HIPCHK(hipMalloc(&ln.d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W));
-        HIPCHK(hipEventCreateWithFlags(&ln.ev_interp_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ln.ev_iter_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ln.ev_out_done, hipEventDisableTiming));
-    }
-    HIPCHK(hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * c->nw * 64 * 4));
-    HIPCHK(hipMemset(c->d_counters, 0, 32));
-    for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) {
-        HIPCHK(hipEventCreate(&c->ev_begin_[i]));
-        HIPCHK(hipEventCreate(&c->ev_end_[i]));
+    c->env_bin_wide = env_on("FLAME_BIN_WIDE");
+    c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
+    c->env_de_gather = env_on("FLAME_DE_GATHER");
+    c->env_de_aos = env_on("FLAME_DE_LDS_AOS");
+    if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
+    else c->own_stream = true;
+    // every failure below leaves through fl_ctx_destroy, which frees whatever exists so far
+    hipError_t e = hipSuccess;
+    const char *what = "context allocation";
+    do {
+        if (c->own_stream)
+            for (int i = 0; i < c->nlanes && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking);
+        if (e) break;
+        if ((e = hipMalloc(&c->d_rng, sizeof(fl_mwc) * (size_t)c->nwalkers))) break;
+        if ((e = hipMalloc(&c->d_points, sizeof(float4) * (size_t)nslots * nw * 64))) break;
+        if ((e = hipMalloc(&c->d_counters, 8 * 4))) break;
+        for (int i = 0; i < c->nlanes && e == hipSuccess; ++i) {
+            Lane &ln = c->lanes[i];
+            if ((e = hipMalloc(&ln.d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W))) break;
+            if ((e = hipEventCreateWithFlags(&ln.ev_interp_done, hipEventDisableTiming))) break;
+            if ((e = hipEventCreateWithFlags(&ln.ev_iter_done, hipEventDisableTiming))) break;
+            if ((e = hipEventCreateWithFlags(&ln.ev_out_done, hipEventDisableTiming))) break;
+        }
+        if (e) break;
+        if ((e = hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemsetD32(c->d_points, 0x7fc00000, (size_t)nslots * nw * 64 * 4))) break;
+        if ((e = hipMemset(c->d_counters, 0, 32))) break;
+        for (uint32_t i = 0; i < fl_ctx::kFrames && e == hipSuccess; ++i) {
+            if ((e = hipEventCreate(&c->ev_begin_[i]))) break;
+            e = hipEventCreate(&c->ev_end_[i]);
+        }
+    } while (0);
+    if (e != hipSuccess) {
+        fl_ctx_destroy(c);
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? FL_E_NOMEM : FL_E_HIP, what, __FILE__, __LINE__, e);
     }
     *out = c;
     return FL_OK;
@@ -239,8 +261,8 @@ void fl_ctx_destroy(fl_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    sync_all(c);
-    for (int i = 0; i < c->nlanes; ++i) {
+    for (int i = 0; i < 2; ++i) if (c->lanes[i].stream) hipStreamSynchronize(c->lanes[i].stream);
+    for (int i = 0; i < 2; ++i) {
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
@@ -248,11 +270,15 @@ void fl_ctx_destroy(fl_ctx *c)
         if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
         if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
-        if (c->own_stream) hipStreamDestroy(ln.stream);
+        if (c->own_stream && ln.stream) hipStreamDestroy(ln.stream);
     }
     hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters);
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) { hipEventDestroy(c->ev_begin_[i]); hipEventDestroy(c->ev_end_[i]); }
+    for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) {
+        if (c->ev_begin_[i]) hipEventDestroy(c->ev_begin_[i]);
+        if (c->ev_end_[i]) hipEventDestroy(c->ev_end_[i]);
+    }
+    (void)hipGetLastError();
     delete c;
 }
 
@@ -304,7 +330,24 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
         const int32_t *o = ops + 4 * i;
         REQUIRE(o[0] >= FL_OP_SPLINE && o[0] <= FL_OP_CONST, "bad op kind");
         REQUIRE(o[1] >= 0 && (uint32_t)o[1] < ps, "op destination out of range");
-        if (o[0] != FL_OP_CONST) { REQUIRE(o[2] >= 0 && (uint32_t)o[2] < nrows, "op row out of range"); continue; }
+        if (o[0] != FL_OP_CONST) {
+            // every word an op writes and every spline row it reads must lie inside the block / row table
+            uint32_t ndst = 1, nsrc = 1;
+            switch (o[0]) {
+            case FL_OP_CAMERA: ndst = 6; nsrc = 4; break;
+            case FL_OP_AFFINE: ndst = 6; nsrc = 6; break;
+            case FL_OP_CDF:
+                REQUIRE(o[3] >= 1 && o[3] <= FL_MAX_XFORMS, "bad CDF length");
+                ndst = nsrc = (uint32_t)o[3];
+                break;
+            case FL_OP_PERSP: ndst = 3; break;
+            default: break;
+            }
+            REQUIRE((uint32_t)o[1] + ndst <= ps, "op destination out of range");
+            REQUIRE(o[2] >= 0 && (uint32_t)o[2] + nsrc <= nrows, "op row out of range");
+            if (o[0] == FL_OP_RATIO2 || o[0] == FL_OP_PERSP) REQUIRE(o[3] >= 0 && (uint32_t)o[3] < nrows, "op row out of range");
+            continue;
+        }
         // structure words: xform word 14 (nvar | post << 8) or a variation number
         const int rel = o[1] - xo;
         REQUIRE(rel >= 0 && rel / xs < nrec, "structure word outside the xform records");
@@ -323,19 +366,27 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
     fl_genome *g = new fl_genome;
     g->prog.assign(prog, prog + nprog);
     g->nops = nops; g->nrows = nrows; g->pstride = ps;
-    HIPCHK(hipMalloc(&g->d_prog, 4 * nprog));
-    HIPCHK(hipMalloc(&g->d_ops, 16 * nops));
-    HIPCHK(hipMalloc(&g->d_times, 4 * (size_t)nrows * FL_KNOTS));
-    HIPCHK(hipMalloc(&g->d_knots, 4 * (size_t)nrows * FL_KNOTS));
-    HIPCHK(hipMalloc(&g->d_ptimes, 4 * FL_KNOTS));
-    HIPCHK(hipMalloc(&g->d_pals, 16 * 256 * FL_KNOTS));
-    HIPCHK(hipMemcpy(g->d_prog, prog, 4 * nprog, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->d_ops, ops, 16 * nops, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(g->d_pals, 0, 16 * 256 * FL_KNOTS));
     g->stage_bytes = 2 * 4 * (size_t)nrows * FL_KNOTS + 16 * 256 * (FL_KNOTS - 1) + 4 * FL_KNOTS;
-    for (int i = 0; i < fl_genome::kStage; ++i) {
-        HIPCHK(hipHostMalloc((void **)&g->h_stage[i], g->stage_bytes, hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&g->ev_stage[i], hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    do {        // a failure anywhere frees what exists so far (fl_genome_destroy tolerates a partial genome)
+        if ((e = hipMalloc(&g->d_prog, 4 * nprog))) break;
+        if ((e = hipMalloc(&g->d_ops, 16 * nops))) break;
+        if ((e = hipMalloc(&g->d_times, 4 * (size_t)nrows * FL_KNOTS))) break;
+        if ((e = hipMalloc(&g->d_knots, 4 * (size_t)nrows * FL_KNOTS))) break;
+        if ((e = hipMalloc(&g->d_ptimes, 4 * FL_KNOTS))) break;
+        if ((e = hipMalloc(&g->d_pals, 16 * 256 * FL_KNOTS))) break;
+        if ((e = hipMemcpy(g->d_prog, prog, 4 * nprog, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemcpy(g->d_ops, ops, 16 * nops, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemset(g->d_pals, 0, 16 * 256 * FL_KNOTS))) break;
+        for (int i = 0; i < fl_genome::kStage && e == hipSuccess; ++i) {
+            if ((e = hipHostMalloc((void **)&g->h_stage[i], g->stage_bytes, hipHostMallocDefault))) break;
+            e = hipEventCreateWithFlags(&g->ev_stage[i], hipEventDisableTiming);
+        }
+    } while (0);
+    if (e != hipSuccess) {
+        fl_genome_destroy(g);
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? FL_E_NOMEM : FL_E_HIP, "genome allocation", __FILE__, __LINE__, e);
     }
     *out = g;
     return FL_OK;
@@ -394,11 +445,22 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     REQUIRE(c && g && g->npal, "genome not uploaded");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
+    // One parameter block per walker slot: slot s iterates temporal sample s of nslots, evaluated
+    // at ts + s*td/nslots, so that every temporal sample receives the same number of iterations
+    // whatever the slot count (the reference: one block column per each of its 1024 temporal
+    // samples, cuburn/render.py:303-307,343-346; cuburn/code/iter.py:165,184).
+    const size_t need = (size_t)c->nslots * g->pstride;
+    if (need > L(c).params_floats) {
+        HIPCHK(hipStreamSynchronize(L(c).stream));
+        hipFree(L(c).d_params); L(c).d_params = nullptr; L(c).params_floats = 0;
+        HIPCHK(hipMalloc(&L(c).d_params, sizeof(float) * need));
+        L(c).params_floats = need;
+    }
     fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * c->nw * 64;
     { int rc = wait_other(c, 0); if (rc) return rc; }     // palette RNG states are shared
     launch_interp_palette(L(c).stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, L(c).d_palette);
     launch_interp_params(L(c).stream, L(c).d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
-                         ts, td / FL_NTEMPORAL, d);
+                         c->nslots, ts, td / (float)c->nslots, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L(c).ev_interp_done, L(c).stream));
     L(c).interp_rec = true;
@@ -427,7 +489,7 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint
     // 128x64 tiles while their number fits the 11 bits left in a staged record (up to 4K);
     // larger images use 256x64 tiles with separately staged tile numbers
     const uint32_t rows = (d.ah + FL_TILE_H - 1) / FL_TILE_H;
-    *wide = ((d.astride + 127) / 128) * rows > FL_MAX_BINS || getenv("FLAME_BIN_WIDE") != nullptr;
+    *wide = ((d.astride + 127) / 128) * rows > FL_MAX_BINS || c->env_bin_wide;
     const uint32_t tw = *wide ? (1u << FL_TILE_W_WIDE_LOG2) : 128u;
     *tiles_x = (d.astride + tw - 1) / tw;
     *nbins = *tiles_x * rows;
@@ -494,6 +556,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
 {
     REQUIRE(c && g, "null argument");
     REQUIRE(accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED || accum_mode == 2, "bad accumulation mode");
+    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -573,8 +636,8 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
-        if (L(c).pend_finish || getenv("FLAME_DE_REFERENCE_FORM") || getenv("FLAME_DE_GATHER")) flush_pending(c);
-        if (getenv("FLAME_DE_REFERENCE_FORM")) {         // the literal per-tap form of the reference kernel
+        if (L(c).pend_finish || c->env_de_reference || c->env_de_gather) flush_pending(c);
+        if (c->env_de_reference) {         // the literal per-tap form of the reference kernel
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur(st, d, L(c).d_blur, L(c).d_front, pat, 0, k7);
                 launch_den_blur_1c(st, d, (float *)L(c).d_side, L(c).d_blur, pat, 1, k7);
@@ -583,7 +646,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             }
             break;
         }
-        if (!getenv("FLAME_DE_GATHER")) {
+        if (!c->env_de_gather) {
             // LDS-tiled form: packed planes PR = (w^dpow, 1/(avg+1e-6)), ping-pong in the side buffer
             const size_t nb2 = (size_t)d.ah * d.astride;
             float *PRa = (float *)L(c).d_side, *PRb = PRa + 2 * nb2;
@@ -593,7 +656,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             else launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur2_lds(st, d, pat, PRa, L(c).d_blur, k7);
-                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
+                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4], !c->env_de_aos);
                 std::swap(Na, Nb); std::swap(PRa, PRb);
             }
             // 8 swaps: the result sits normalised in Na == d_back; un-normalising it into d_front
@@ -751,7 +814,7 @@ static int buf_ptr(fl_ctx *c, fl_genome *g, int which, void **p, size_t *cap)
     case FL_BUF_FRONT: *p = L(c).d_front; *cap = 16 * L(c).nbins; break;
     case FL_BUF_BACK: *p = L(c).d_back; *cap = 16 * L(c).nbins; break;
     case FL_BUF_SIDE: *p = L(c).d_side; *cap = 16 * L(c).nbins; break;
-    case FL_BUF_PARAMS: *p = L(c).d_params; *cap = 4 * (size_t)FL_NTEMPORAL * (g ? g->pstride : FL_MAX_PSTRIDE); break;
+    case FL_BUF_PARAMS: *p = L(c).d_params; *cap = 4 * L(c).params_floats; break;
     case FL_BUF_PALETTE: *p = L(c).d_palette; *cap = 8 * FL_PAL_H * FL_PAL_W; break;
     case FL_BUF_POINTS: *p = c->d_points; *cap = 16 * (size_t)c->nslots * c->nw * 64; break;
     case FL_BUF_SEEDS: *p = c->d_rng; *cap = sizeof(fl_mwc) * (size_t)c->nwalkers; break;
@@ -817,6 +880,7 @@ int fl_debug_iter_launch(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, uint32
                          uint32_t nrounds, uint32_t fuse, int accum_mode)
 {
     REQUIRE(c && g && (accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED), "bad argument");
+    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -844,34 +908,40 @@ int fl_debug_clear_hot(fl_ctx *c, uint32_t w, uint32_t h)
     return FL_OK;
 }
 
+// scratch device memory of a debug tap, freed on every exit path
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n); }
+};
+
 int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)
 {
     REQUIRE(c && out256, "null argument");
     HIPCHK(hipSetDevice(c->device));
-    uint32_t *d; const size_t n = (size_t)c->nw * 64;
-    HIPCHK(hipMalloc(&d, 4 * n));
-    launch_shuffle_tap(L(c).stream, c->nw, d, round);
+    DevBuf d; const size_t n = (size_t)c->nw * 64;
+    HIPCHK(d.alloc(4 * n));
+    launch_shuffle_tap(L(c).stream, c->nw, (uint32_t *)d.p, round);
     HIPCHK(hipStreamSynchronize(L(c).stream));
-    HIPCHK(hipMemcpy(out256, d, 4 * n, hipMemcpyDeviceToHost));
-    hipFree(d);
+    HIPCHK(hipMemcpy(out256, d.p, 4 * n, hipMemcpyDeviceToHost));
     return FL_OK;
 }
 
 int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng)
 {
-    REQUIRE(c && g && xyzw && rng && n > 0 && ts < FL_NTEMPORAL, "bad argument");
+    REQUIRE(c && g && xyzw && rng && n > 0 && ts < c->nslots, "bad argument");
     REQUIRE(xfi >= 0 && xfi < g->prog[1] + g->prog[2], "xform index out of range");
+    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
-    float4 *dp; fl_mwc *dr;
-    HIPCHK(hipMalloc(&dp, 16 * (size_t)n));
-    HIPCHK(hipMalloc(&dr, sizeof(fl_mwc) * (size_t)n));
-    HIPCHK(hipMemcpy(dp, xyzw, 16 * (size_t)n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dr, rng, sizeof(fl_mwc) * (size_t)n, hipMemcpyHostToDevice));
-    launch_apply_xf_tap(L(c).stream, g->d_prog, L(c).d_params, ts, xfi, n, dp, dr);
+    DevBuf dp, dr;
+    HIPCHK(dp.alloc(16 * (size_t)n));
+    HIPCHK(dr.alloc(sizeof(fl_mwc) * (size_t)n));
+    HIPCHK(hipMemcpy(dp.p, xyzw, 16 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr.p, rng, sizeof(fl_mwc) * (size_t)n, hipMemcpyHostToDevice));
+    launch_apply_xf_tap(L(c).stream, g->d_prog, L(c).d_params, ts, xfi, n, (float4 *)dp.p, (fl_mwc *)dr.p);
     HIPCHK(hipStreamSynchronize(L(c).stream));
-    HIPCHK(hipMemcpy(xyzw, dp, 16 * (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rng, dr, sizeof(fl_mwc) * (size_t)n, hipMemcpyDeviceToHost));
-    hipFree(dp); hipFree(dr);
+    HIPCHK(hipMemcpy(xyzw, dp.p, 16 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rng, dr.p, sizeof(fl_mwc) * (size_t)n, hipMemcpyDeviceToHost));
     return FL_OK;
 }
 

@@ -3,7 +3,8 @@
 //  * k_interp_params : cuburn/code/interp.py:234-272 (interp_iter_params) + the precalc
 //    snippets of cuburn/code/iter.py:12-30,56-95 and cuburn/code/variations.py
 //    (:136-140, :267-273, :292-294, :630-634), driven by the op list of
-//    include/flame_hip.h (6) instead of generated code.  One thread per (temporal sample, op).
+//    include/flame_hip.h (6) instead of generated code.  One thread per (temporal sample, op);
+//    there is one temporal sample per walker slot (nts = nslots, see iter.hip).
 //  * k_interp_palette: cuburn/code/interp.py:372-433 (interp_color + interp_palette_flat);
 //    writes the packed-u64 palette (256 x 64) into plain global memory (the reference's
 //    CUDA surface has no CDNA equivalent; the iterate kernel stages its row in LDS).
@@ -60,14 +61,14 @@ __device__ float catmull_rom(const float *times, const float *knots, float t, bo
 
 __global__ void __launch_bounds__(256)
 k_interp_params(float *__restrict__ params, const float *__restrict__ times, const float *__restrict__ knots,
-                const int4 *__restrict__ ops, uint32_t nops, uint32_t pstride, float tstart, float tstep,
+                const int4 *__restrict__ ops, uint32_t nops, uint32_t pstride, uint32_t nts, float tstart, float tstep,
                 fl_dim dim)
 {
     // grid (temporal samples / 256, ops): one thread evaluates ONE op of one temporal sample (ops
     // write disjoint words of the block; the launcher zero-fills the padding first).  One thread
     // per sample walking the whole op list was a 40 us serial chain at the head of every frame.
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= FL_NTEMPORAL) return;
+    if (id >= nts) return;
     const float time = tstart + (float)id * tstep;
     float *out = params + (size_t)id * pstride;
 #define ROW(r, mag) catmull_rom(times + (size_t)(r) * FL_KNOTS, knots + (size_t)(r) * FL_KNOTS, time, mag)
@@ -165,10 +166,10 @@ void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes,
 }
 
 void launch_interp_params(hipStream_t st, float *params, const float *times, const float *knots,
-                          const int32_t *ops, uint32_t nops, uint32_t pstride, float ts, float tstep, fl_dim dim)
+                          const int32_t *ops, uint32_t nops, uint32_t pstride, uint32_t nts, float ts, float tstep, fl_dim dim)
 {
-    hipMemsetAsync(params, 0, sizeof(float) * (size_t)FL_NTEMPORAL * pstride, st);     // padding / unused post affines
+    hipMemsetAsync(params, 0, sizeof(float) * (size_t)nts * pstride, st);     // padding / unused post affines
     if (nops == 0) return;
-    hipLaunchKernelGGL(k_interp_params, dim3(FL_NTEMPORAL / 256, nops), dim3(256), 0, st, params, times, knots,
-                       (const int4 *)ops, nops, pstride, ts, tstep, dim);
+    hipLaunchKernelGGL(k_interp_params, dim3((nts + 255) / 256, nops), dim3(256), 0, st, params, times, knots,
+                       (const int4 *)ops, nops, pstride, nts, ts, tstep, dim);
 }

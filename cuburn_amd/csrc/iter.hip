@@ -4,7 +4,11 @@
 // (cuburn/code/iter.py:157-418, :420-544) with precompiled kernels that interpret the
 // xform program of include/flame_hip.h (5).  MI355X mapping:
 //   * workgroup = NW waves x 64 lanes, one walker per lane, bound to a persistent slot
-//     (slot = blockIdx.x; temporal sample = slot & 1023, palette row = that >> 4);
+//     (slot = blockIdx.x).  The reference runs one block column per temporal sample (grid
+//     (1024, n), iter.py:165,184; render.py:343-346), i.e. every temporal sample gets the same
+//     number of iterations; here there are as many temporal samples as slots (fl_interp
+//     evaluates nslots parameter blocks at ts + s*td/nslots), slot s uses block s and palette
+//     row s*64/nslots — equal weights for any slot count;
 //   * xform selection is per WAVE: every lane draws, lane 0's draw is broadcast with
 //     v_readfirstlane, so the xform branch and all parameter loads are scalar;
 //   * walkers change wave every round through a double-buffered LDS swap (one barrier per
@@ -141,12 +145,12 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const uint32_t slot = blockIdx.x, ts = slot % FL_NTEMPORAL;
+    const uint32_t slot = blockIdx.x, ts = slot, prow = slot * FL_PAL_H / gridDim.x;
     const int nxf = prog[1], has_final = prog[2], pstride = prog[3], cdf_off = prog[4];
     const int xf_off = prog[5], xf_stride = prog[6], var_stride = prog[7];
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
-    if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[(ts >> 4) * FL_PAL_W + i];
+    if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[prow * FL_PAL_W + i];
     if (BINNED) for (uint32_t i = tid; i <= bg.nbins; i += NT) cnt[i] = 0;
     uint32_t staged = 0, batch_in_slot = 0;
 
@@ -406,8 +410,8 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
     BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total};
     const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins);
 #define LAUNCH(NW, C, A) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { hipFuncSetAttribute((const void *)k_iter<NW, C, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        static unsigned long long attr_done = 0; \
+        ensure_max_dynamic_lds((const void *)k_iter<NW, C, A>, attr_done); \
         /* the timing events bracket the kernel itself (recorded by the dispatch packet), not the launch call */ \
         hipExtLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, ev_start, ev_stop, 0, prog, params, palette, \
         rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg, log, dir); } while (0)

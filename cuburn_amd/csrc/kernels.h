@@ -6,6 +6,17 @@
 
 typedef unsigned long long u64;
 
+// hipFuncSetAttribute is per DEVICE: raise a kernel's dynamic-LDS cap once on every device it is
+// launched on (a process may hold contexts on several GPUs).  `done` is a per-kernel bit mask.
+static inline void ensure_max_dynamic_lds(const void *fn, unsigned long long &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+    if (done >> dev & 1ull) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (dev != 63) done |= 1ull << dev;
+}
+
 // iter.hip
 void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
@@ -29,7 +40,7 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
 void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes, const float4 *pals,
                            float ts, float tstep, u64 *out);
 void launch_interp_params(hipStream_t st, float *params, const float *times, const float *knots,
-                          const int32_t *ops, uint32_t nops, uint32_t pstride, float ts, float tstep,
+                          const int32_t *ops, uint32_t nops, uint32_t pstride, uint32_t nts, float ts, float tstep,
                           fl_dim dim);
 
 // filters.hip
@@ -49,7 +60,7 @@ void launch_yuv_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *
 void launch_de_finish_tone(hipStream_t st, fl_dim d, float4 *dst, const float4 *N, bool do_log, float k1, float k2, bool do_clip, const float *cc5);
 void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *coefs7);
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
-                             float sstd, float cstd, float dstd, float dpow, float gspeed);
+                             float sstd, float cstd, float dstd, float dpow, float gspeed, bool packed);
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float highpow, float gam, float lin, float lingam);
 void launch_gamma_full_hi(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);

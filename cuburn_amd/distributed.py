@@ -40,19 +40,36 @@ def gather_frame(frame, dst=0):
     return out
 
 
-def gather_animation(local_frames, nframes, dst=0):
+def gather_animation(local_frames, nframes, dst=0, shape=None, dtype=None, device=None):
     """
     ``local_frames``: this rank's frames in shard order (tensors of one shape).  Returns the
     full animation in frame order on ``dst`` (list of tensors), None elsewhere.  Ranks whose
-    shard is one frame short contribute a dummy in the last round.
+    shard is one frame short contribute a dummy in the last round; a rank whose shard is EMPTY
+    (nframes < world) has no frame to take the shape from, so the shape / dtype / device travel
+    explicitly or are broadcast from the first rank, which always owns frame 0.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
+    if nframes <= 0:
+        return [] if rank == dst else None
     rounds = (nframes + world - 1) // world
     result = [None] * nframes if rank == dst else None
     proto = local_frames[0] if local_frames else None
+    if world > 1 and shape is None:
+        meta = [None]
+        if rank == 0:
+            meta = [(tuple(proto.shape), proto.dtype, str(proto.device))]
+        dist.broadcast_object_list(meta, src=0)
+        shape, dtype, dev = meta[0]
+        if device is None:
+            device = proto.device if proto is not None else (torch.device('cpu') if dev == 'cpu' else torch.device('cuda', torch.cuda.current_device()))
     for k in range(rounds):
-        f = local_frames[k] if k < len(local_frames) else torch.zeros_like(proto)
+        if k < len(local_frames):
+            f = local_frames[k]
+        elif proto is not None:
+            f = torch.zeros_like(proto)
+        else:
+            f = torch.zeros(shape, dtype=dtype, device=device)
         got = gather_frame(f, dst)
         if rank == dst:
             for r, t in enumerate(got):
@@ -103,12 +120,22 @@ class _DeviceArray(object):
                                              data=(int(ptr), False), version=2)
 
 
-def accumulator_tensor(fb, device):
-    """The float4[nbins] accumulator of the current frame as a flat float32 torch tensor."""
+def accumulator_tensor(fb, device, dim=None):
+    """
+    The float4 accumulator of the current frame as a flat float32 torch tensor.  The native
+    buffers only ever grow, so their capacity depends on a rank's allocation history: with ``dim``
+    the view covers exactly the frame's ah x astride cells, which is what every rank must hand to
+    the all-reduce.
+    """
     from . import _lib
     p, n = C.c_void_p(), C.c_size_t()
     _lib.check(_lib.load().fl_buffer_ptr(fb.ctx, None, _lib.BUF['front'], C.byref(p), C.byref(n)))
-    return torch.as_tensor(_DeviceArray(p.value, n.value // 4), device=torch.device('cuda', device))
+    nfloats = n.value // 4
+    if dim is not None:
+        want = int(dim.ah) * int(dim.astride) * 4
+        assert want <= nfloats
+        nfloats = want
+    return torch.as_tensor(_DeviceArray(p.value, nfloats), device=torch.device('cuda', device))
 
 
 def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True):
@@ -140,11 +167,11 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True):
                               mgr.resolve_accum_mode(dim), C.byref(run)))
     mgr.last_nsamples = run.value
     if world > 1:
-        acc = accumulator_tensor(fb, device)      # waits for the iterate + flush kernels
+        acc = accumulator_tensor(fb, device, dim)      # waits for the iterate + flush kernels
         sum_accumulators(acc)
         torch.cuda.synchronize(device)
     for filt in rdr.filts:
         filt.apply(fb, gprof, getattr(gprof.filters, filt.name), dim, tc)
     rdr.out.convert(fb, gprof, dim)
     h_out = rdr.out.copy(fb, dim)
-    return DurationEvent(fb.ctx, fid.value), h_out
+    return DurationEvent(fb, fid.value), h_out

@@ -8,6 +8,7 @@ in libflame_hip.so through the C ABI of include/flame_hip.h.
 """
 import ctypes as C
 import os
+import weakref
 from collections import namedtuple
 
 import numpy as np
@@ -21,23 +22,46 @@ Dimensions = namedtuple('Dimensions', 'w h aw ah astride')
 
 
 class DurationEvent(object):
-    """Completion handle of one queued frame (cuburn/render.py:26-38)."""
+    """
+    Completion handle of one queued frame (cuburn/render.py:26-38).
 
-    def __init__(self, ctx, frame_id):
-        self._ctx, self._id = ctx, frame_id
+    The handle refers to a frame of the native context that ``fb`` owned when the frame was
+    queued.  Framebuffers re-creates that context when the image size asks for the other walker
+    geometry: it first resolves every outstanding handle (``_finalise``), so a handle never
+    touches a context that has been destroyed.
+    """
+
+    def __init__(self, fb, frame_id):
+        self._fb, self._id = fb, frame_id
+        self._gen = fb.generation
         self._ms = None
+        fb._track(self)
+
+    def _call(self, fn, *args):
+        if self._fb is None or self._gen != self._fb.generation or self._fb._ctx is None:
+            raise _lib.FlameError('frame %d belongs to a render context that no longer exists' % self._id)
+        return fn(self._fb._ctx, self._id, *args)
+
+    def _finalise(self):
+        """Resolve the frame time while the context still exists (called before it is dropped)."""
+        if self._ms is None:
+            try:
+                self.synchronize()
+            except Exception:
+                self._ms = float('nan')             # e.g. more than 4 frames old: no longer tracked
+        self._fb = None
 
     def synchronize(self):
         if self._ms is None:
             ms = C.c_float()
-            _lib.check(_lib.load().fl_frame_ms(self._ctx, self._id, C.byref(ms)))
+            _lib.check(self._call(_lib.load().fl_frame_ms, C.byref(ms)))
             self._ms = ms.value
         return self
 
     def query(self):
         if self._ms is not None:
             return True
-        rc = _lib.load().fl_frame_query(self._ctx, self._id)
+        rc = self._call(_lib.load().fl_frame_query)
         if rc < 0:
             _lib.check(rc)
         return rc == 1
@@ -80,6 +104,7 @@ class Framebuffers(object):
         self.nout = 65536                   # RNG states of the output dither kernel
         self._host = {}
         self._pinned_ptrs = []
+        self._events = []                   # weak references to unresolved DurationEvents of this context
         self.ctx                            # create now: no GPU / no library must fail here, loudly
 
     nw = property(lambda self: self._cfg[0])             # waves per iterate workgroup
@@ -127,9 +152,18 @@ class Framebuffers(object):
                 self._cfg = want
         return dim
 
+    def _track(self, evt):
+        self._events = [r for r in self._events if r() is not None and r()._ms is None][-8:]
+        self._events.append(weakref.ref(evt))
+
     def _drop_ctx(self):
         if self._ctx is not None:
             _lib.load().fl_ctx_sync(self._ctx)
+            for r in self._events:                      # resolve handles that still point into this context
+                evt = r()
+                if evt is not None:
+                    evt._finalise()
+            self._events = []
             _lib.load().fl_ctx_destroy(self._ctx)
             self._ctx = None
             self.generation += 1
@@ -265,7 +299,7 @@ class RenderManager(object):
             filt.apply(self.fb, gprof, params, dim, tc)
         rdr.out.convert(self.fb, gprof, dim)
         h_out = rdr.out.copy(self.fb, dim)
-        return DurationEvent(self.fb.ctx, fid.value), h_out
+        return DurationEvent(self.fb, fid.value), h_out
 
     def timings_reset(self):
         _lib.check(_lib.load().fl_timings_reset(self.fb.ctx))

@@ -58,7 +58,8 @@ typedef struct fl_mwc {
  *     values; normalisation per cuburn/genome/use.py:129-158.
  */
 #define FL_KNOTS 32
-#define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples */
+#define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples = the minimum slot count here: there is one
+                               temporal sample per walker slot (fl_ctx_create nslots >= 1024), see fl_interp */
 #define FL_PAL_W 256        /* cuburn/render.py:201-202 palette surface 256 x 64 */
 #define FL_PAL_H 64
 #define FL_GUTTER 12        /* cuburn/render.py:77 */
@@ -160,7 +161,11 @@ int fl_genome_upload(fl_ctx *ctx, fl_genome *g, const float *times, const float 
                      const float *pal_rgba, const float *pal_times, uint32_t npal);
 
 /* cuburn/render.py:289-307 RenderManager._interp: interp_palette_flat + interp_iter_params
- * for the frame window [ts, ts+td). */
+ * for the frame window [ts, ts+td).  The reference evaluates 1024 temporal samples and runs one
+ * block column per sample (grid (1024, n), render.py:343-346), so every sample gets the same number
+ * of iterations.  Here the number of temporal samples equals the number of walker slots: block s
+ * (s < nslots) is evaluated at ts + s*td/nslots and iterated by slot s, palette row r (of 64) at
+ * ts + r*td/64 is used by slots [r*nslots/64, (r+1)*nslots/64) — equal weights for any nslots. */
 int fl_interp(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, float ts, float td);
 
 /* Accumulation back-ends for fl_iterate. */
@@ -218,7 +223,7 @@ int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, u
 enum {
     FL_BUF_FRONT = 0,   /* float4[nbins]  accumulator / filter result (render.py:44-48)  */
     FL_BUF_BACK = 1,    /* float4[nbins]                                                   */
-    FL_BUF_PARAMS = 2,  /* float[FL_NTEMPORAL * pstride] interpolated parameter blocks     */
+    FL_BUF_PARAMS = 2,  /* float[nslots * pstride] interpolated parameter blocks (one per slot) */
     FL_BUF_PALETTE = 3, /* u64[FL_PAL_H * FL_PAL_W] packed palette (interp.py:409-433)     */
     FL_BUF_POINTS = 4,  /* float4[nwalkers] walker points (render.py:102-104)              */
     FL_BUF_SEEDS = 5,   /* fl_mwc[nwalkers]                                                */

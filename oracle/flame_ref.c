@@ -765,8 +765,11 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
     return 0;
 }
 
-/* All slots of one launch.  Slot s uses temporal sample s & 1023 and palette row
- * (s & 1023) >> 4 (cuburn/code/iter.py:165,184). */
+/* All slots of one launch.  The reference runs one block column per temporal sample (grid
+ * (1024, n), cuburn/code/iter.py:165,184; cuburn/render.py:343-346), so every temporal sample
+ * receives the same number of iterations.  The device model keeps that property for any slot
+ * count: there are as many temporal samples as slots (`params` holds nslots blocks, block s
+ * evaluated at ts + s*td/nslots), slot s uses block s and palette row s*64/nslots. */
 int ref_iter_launch(const ref_geom *g, const ref_dim *dim, const int32_t *prog, const float *params,
                     const uint64_t *palette, ref_mwc *rng, float *points, uint32_t nslots,
                     const uint32_t *hot, uint64_t *atom, float *out4,
@@ -775,8 +778,8 @@ int ref_iter_launch(const ref_geom *g, const ref_dim *dim, const int32_t *prog, 
     const int nt = g->nw * g->wl;
     int pstride = prog[3];
     for (uint32_t s = 0; s < nslots; ++s) {
-        uint32_t ts = s % 1024;
-        if (iter_block(g, dim, prog, params + (size_t)ts * pstride, palette + (ts >> 4) * 256,
+        uint32_t ts = s;
+        if (iter_block(g, dim, prog, params + (size_t)ts * pstride, palette + (size_t)((uint64_t)s * 64 / nslots) * 256,
                        rng + (size_t)s * nt, points + (size_t)s * nt * 4, hot, atom, out4,
                        round0, nrounds, fuse, counters))
             return -1;
@@ -812,7 +815,7 @@ void ref_flush(const ref_dim *dim, uint64_t *atom, float *out4, uint32_t *hot)
 /* ------------------------------------------------------------------ flam3-style baseline */
 typedef struct f3_job {
     const ref_dim *dim; const int32_t *prog; const float *params; const float *palf;
-    ref_mwc rng; uint64_t nsamples; int fuse; float *hist; uint64_t accepted; int tid; int nthreads;
+    ref_mwc rng; uint64_t nsamples; int fuse; float *hist; uint64_t accepted; int tid; int nthreads; uint32_t nts;
     struct f3_job *all; pthread_barrier_t *bar; float *out4;
 } f3_job;
 
@@ -827,13 +830,18 @@ static void *f3_worker(void *arg)
     ref_mwc *r = &j->rng;
     float x = ref_mwc_next_11(r), y = ref_mwc_next_11(r), c = ref_mwc_next_01(r);
     int fuse = j->fuse;
-    uint64_t done = 0, chunk = 0;
-    while (done < j->nsamples) {
-        /* one temporal sample per 4096-iteration chunk, interleaved across threads */
-        uint32_t ts = (uint32_t)((chunk * j->nthreads + j->tid) & 1023);
+    /* The job's samples are cut into nchunks = nts * k chunks of (almost) equal length, chunk c
+     * belongs to temporal sample c % nts and to thread c % nthreads: every temporal sample gets the
+     * same number of iterations (cuburn/render.py:343-346: one block column per temporal sample). */
+    const uint64_t total = j->nsamples;
+    uint64_t per_ts = (total + 2048ull * j->nts) / (4096ull * j->nts);
+    if (per_ts < 1) per_ts = 1;
+    const uint64_t nchunks = per_ts * j->nts;
+    for (uint64_t chunk = (uint64_t)j->tid; chunk < nchunks; chunk += (uint64_t)j->nthreads) {
+        uint32_t ts = (uint32_t)(chunk % j->nts);
         const float *P = j->params + (size_t)ts * pstride;
-        const float *pal = j->palf + (size_t)(ts >> 4) * 256 * 3;
-        uint64_t n = j->nsamples - done < 4096 ? j->nsamples - done : 4096;
+        const float *pal = j->palf + (size_t)((uint64_t)ts * 64 / j->nts) * 256 * 3;
+        uint64_t n = total / nchunks + (chunk < total % nchunks);
         for (uint64_t i = 0; i < n + (uint64_t)fuse; ++i) {
             if (!isfinite(fabsf(x) + fabsf(y))) { x = ref_mwc_next_11(r); y = ref_mwc_next_11(r); c = ref_mwc_next_01(r); }
             int k = select_xf(prog, P, ref_mwc_next_01(r));
@@ -852,8 +860,6 @@ static void *f3_worker(void *arg)
             j->accepted++;
         }
         fuse = 0;
-        done += n;
-        chunk++;
     }
     /* merge: every worker sums one stripe of the image over all private histograms */
     pthread_barrier_wait(j->bar);
@@ -870,7 +876,7 @@ static void *f3_worker(void *arg)
 /* Classic flam3-style chaos game: every walker draws its own xform each iteration
  * (no wave coherence, no point swap), one private float histogram per thread (allocated and
  * merged in parallel).  Returns the wall seconds of iterate + merge.  out4 is ADDED to. */
-double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *params,
+double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *params, uint32_t nts,
                         const uint64_t *palette, const ref_mwc *seeds, uint32_t nseeds,
                         uint64_t nsamples, int nthreads, int fuse, float *out4, uint64_t *accepted)
 {
@@ -885,8 +891,8 @@ double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *pa
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, nthreads);
     for (int t = 0; t < nthreads; ++t) {
-        jobs[t] = (f3_job){dim, prog, params, palf, seeds[t % nseeds], nsamples / nthreads + (t < (int)(nsamples % nthreads)),
-                           fuse, NULL, 0, t, nthreads, jobs, &bar, out4};
+        jobs[t] = (f3_job){dim, prog, params, palf, seeds[t % nseeds], nsamples,
+                           fuse, NULL, 0, t, nthreads, nts, jobs, &bar, out4};
     }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

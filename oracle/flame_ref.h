@@ -63,7 +63,7 @@ void ref_flush(const ref_dim *dim, uint64_t *atom, float *out4, uint32_t *hot);
 void ref_unpack_cell(uint64_t cell, uint32_t out[4]);
 
 /* flam3-style per-sample-selection chaos game: CPU baseline */
-double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *params,
+double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *params, uint32_t nts,
                         const uint64_t *palette, const ref_mwc *seeds, uint32_t nseeds,
                         uint64_t nsamples, int nthreads, int fuse, float *out4, uint64_t *accepted);
 

@@ -60,7 +60,7 @@ def lib():
         L.ref_catmull_rom.restype = C.c_float
         L.ref_catmull_rom.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int]
         L.ref_flam3_render.restype = C.c_double
-        L.ref_flam3_render.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_flam3_render.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2 + [C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_iter_launch.restype = C.c_int
         L.ref_iter_launch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 3 + [C.c_uint32] * 3 + [C.c_void_p]
         L.ref_interp_palette.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
@@ -145,7 +145,10 @@ def interp_palette(pal_rgba, pal_times, ts, td, rng64x256):
 
 def iter_launch(geom, dim, prog, params, palette, rng, points, nslots, hot, atom, out4,
                 round0, nrounds, fuse):
-    """In-place on rng, points, atom, out4; returns counters [accepted, oob, dropped, spills]."""
+    """In-place on rng, points, atom, out4; returns counters [accepted, oob, dropped, spills].
+    ``params`` holds one block per slot (temporal sample s = slot s)."""
+    assert params.shape[0] == nslots, 'one parameter block per slot'
+    params = np.ascontiguousarray(params, dtype=np.float32)
     ctr = np.zeros(4, dtype=np.uint64)
     prog = np.ascontiguousarray(prog, dtype=np.int32)
     rc = lib().ref_iter_launch(C.byref(geom), C.byref(dim), _p(prog), _p(params), _p(palette), _p(rng),
@@ -160,13 +163,16 @@ def flush(dim, atom, out4, hot):
 
 
 def flam3_render(dim, prog, params, palette, seeds, nsamples, nthreads, fuse=15):
-    """flam3-style CPU chaos game; returns (float4 histogram, seconds, accepted)."""
+    """flam3-style CPU chaos game; returns (float4 histogram, seconds, accepted).
+    ``params`` holds one block per temporal sample (any count); all get equal weight."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    assert params.ndim == 2
     nbins = dim.ah * dim.astride
     out = np.zeros((nbins, 4), dtype=np.float32)
     acc = C.c_uint64()
     prog = np.ascontiguousarray(prog, dtype=np.int32)
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
-    secs = lib().ref_flam3_render(C.byref(dim), _p(prog), _p(params), _p(palette), _p(seeds), len(seeds),
+    secs = lib().ref_flam3_render(C.byref(dim), _p(prog), _p(params), params.shape[0], _p(palette), _p(seeds), len(seeds),
                                   int(nsamples), int(nthreads), int(fuse), _p(out), C.byref(acc))
     return out, secs, acc.value
 

@@ -20,15 +20,16 @@ def frame_times(gprof, tc):
     return tc - 0.5 * td, td
 
 
-def oracle_params(gnm, packer, dim, ts, td):
-    """Parameter blocks of all 1024 temporal samples computed by the oracle (by name)."""
+def oracle_params(gnm, packer, dim, ts, td, nts=1024):
+    """Parameter blocks of all ``nts`` temporal samples computed by the oracle (by name).  The
+    device evaluates one block per walker slot (block i at ts + i*td/nts)."""
     names = ['.'.join(n) for n in packer.packed]
-    out = np.zeros((1024, packer.pstride), dtype=np.float32)
+    out = np.zeros((nts, packer.pstride), dtype=np.float32)
     if td == 0:
         out[:] = O.param_block(gnm, names, np.float32(ts), dim).astype(np.float32)
     else:
-        tstep = np.float32(td / 1024)
-        for i in range(1024):
+        tstep = np.float32(np.float32(td) / np.float32(nts))
+        for i in range(nts):
             t = np.float32(ts) + np.float32(i) * tstep
             out[i] = O.param_block(gnm, names, float(t), dim).astype(np.float32)
     # the last cumulative density takes whatever is left (>= 1 on device)
@@ -48,7 +49,7 @@ def prepare(gnm, prof, tc=0.5, nslots=1024, host_seed=42):
     dim = O.calc_dim(gprof.width, gprof.height)
     ts, td = frame_times(gprof, tc)
     seeds = mwc.make_seeds((nslots + 64) * 256, host_seed)
-    params = oracle_params(gnm, packer, dim, ts, td)
+    params = oracle_params(gnm, packer, dim, ts, td, nslots)
     palette, rng_pal = oracle_palette(gnm, ts, td, seeds[nslots * 256:])
     return dict(gprof=gprof, packer=packer, dim=dim, ts=ts, td=td, seeds=seeds, params=params,
                 palette=palette, rng_pal_after=rng_pal, nslots=nslots)

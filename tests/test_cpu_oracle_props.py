@@ -37,7 +37,8 @@ def run_model(F, geom, rounds, fuse, seeds=None):
     rng = (mwc.make_seeds(F['nslots'] * nt, 3) if seeds is None else seeds).copy()
     pts = np.full((F['nslots'] * nt, 4), np.nan, np.float32)
     hot = np.zeros(nb // 16, np.uint32); atom = np.zeros(nb, np.uint64); out4 = np.zeros((nb, 4), np.float32)
-    ctr = O.iter_launch(geom, d, F['packer'].prog, F['params'], F['palette'], rng, pts, F['nslots'], hot, atom, out4,
+    # one parameter block per slot (stills: all blocks are equal)
+    ctr = O.iter_launch(geom, d, F['packer'].prog, F['params'][:F['nslots']], F['palette'], rng, pts, F['nslots'], hot, atom, out4,
                         0, rounds + fuse, fuse)
     return ctr, atom, out4, hot, rng, pts
 

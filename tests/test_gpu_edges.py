@@ -148,6 +148,85 @@ def test_argument_validation(mgr):
                                 packer.nrows, C.byref(h)) == _lib.FL_E_INVAL
 
 
+def test_malformed_op_lists_rejected(mgr):
+    """Every word an op writes and every spline row it reads is checked against the block / row
+    table at fl_genome_create (multi-word ops: camera / affine 6 words, CDF b words, perspective 3)."""
+    lib = _lib.load()
+    gnm, prof = nxf_flame(3)
+    packer = GenomePacker(gnm)
+    prog = np.array(packer.prog, np.int32)
+    good = np.ascontiguousarray(packer.ops_array, np.int32).reshape(-1, 4)
+    ps, nrows = int(prog[3]), packer.nrows
+
+    def create(ops):
+        ops = np.ascontiguousarray(ops, np.int32)
+        h = C.c_void_p()
+        rc = lib.fl_genome_create(mgr.fb.ctx, prog.ctypes.data, len(prog), ops.ctypes.data, len(ops), nrows, C.byref(h))
+        if rc == 0:
+            lib.fl_genome_destroy(h)
+        return rc
+
+    assert create(good) == 0
+    kinds = good[:, 0]
+    cam = int(np.where(kinds == 2)[0][0]); aff = int(np.where(kinds == 3)[0][0]); cdf = int(np.where(kinds == 4)[0][0])
+    for idx, col, val in ((cam, 1, ps - 3),             # camera writes 6 words: would run past the block
+                          (cam, 2, nrows - 2),          # ... and reads 4 rows
+                          (aff, 1, ps - 5), (aff, 2, nrows - 5),
+                          (cdf, 3, 65), (cdf, 3, 0), (cdf, 2, nrows - 1), (cdf, 1, ps - 1)):
+        bad = good.copy()
+        bad[idx, col] = val
+        assert create(bad) == _lib.FL_E_INVAL, (idx, col, val)
+    extra = np.vstack([good, [[7, ps - 2, 0, 0]]])      # perspective writes 3 words
+    assert create(extra) == _lib.FL_E_INVAL
+    extra = np.vstack([good, [[5, 6, 0, nrows]]])       # ratio2: second row index out of range
+    assert create(extra) == _lib.FL_E_INVAL
+
+
+def test_out_of_memory_is_survivable(mgr):
+    """cuburn/render.py:140-147: an allocation failure frees the framebuffers and re-raises; the
+    manager stays usable.  A 200000 x 200000 frame (640 GB per float4 buffer) cannot be allocated:
+    the C ABI reports FL_E_NOMEM (MemoryError in Python), and a normal frame renders afterwards."""
+    lib = _lib.load()
+    gnm, prof = configs.cfg2(samples=2 ** 22)
+    small = dict(prof, width=320, height=180, spp=2 ** 22 / (320.0 * 180.0))
+    gp = profile.wrap(small, gnm)
+    rdr = render.Renderer(gnm, gp)
+    evt, out = mgr.queue_frame(rdr, gnm, gp, 0.5); evt.synchronize()
+    before = np.array(out).astype(np.float64)
+    g = rdr._handle(mgr.fb)
+    run = C.c_uint64()
+    assert lib.fl_iterate(mgr.fb.ctx, g, 200000, 200000, 1e6, 4, 1, C.byref(run)) == _lib.FL_E_NOMEM
+    assert b'allocation' in lib.fl_last_error()
+    huge = profile.wrap(dict(prof, width=200000, height=200000, spp=1e-4), gnm)
+    with pytest.raises(MemoryError):
+        mgr.queue_frame(render.Renderer(gnm, huge), gnm, huge, 0.5)
+    evt, out = mgr.queue_frame(rdr, gnm, gp, 0.5); evt.synchronize()
+    after = np.array(out).astype(np.float64)
+    assert after[..., 3].max() > 100 and np.abs(after - before).mean() < 6.0
+
+
+def test_duration_event_outlives_a_context_switch():
+    """In auto geometry a change of image size re-creates the native context; a DurationEvent of
+    a frame queued before the switch is resolved first and stays readable (it used to keep a
+    dangling fl_ctx*)."""
+    m = render.RenderManager(device=0, host_seed=5)
+    gnm, prof = configs.cfg2(samples=2 ** 24)
+    small = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 24 / (640.0 * 360.0)), gnm)
+    big = profile.wrap(dict(prof, width=7680, height=4320, spp=2 ** 26 / (7680.0 * 4320.0)), gnm)
+    rdr_s, rdr_b = render.Renderer(gnm, small), render.Renderer(gnm, big)
+    evt_a, a = m.queue_frame(rdr_s, gnm, small, 0.5)         # NOT synchronised: the double-buffered loop
+    gen = m.fb.generation
+    evt_b, b = m.queue_frame(rdr_b, gnm, big, 0.5)           # switches to the 8-wave geometry
+    assert m.fb.generation == gen + 1
+    assert evt_a.query() is True and evt_a.time() > 0         # resolved before the old context went away
+    assert np.array(a)[..., 3].max() > 0
+    evt_b.synchronize()
+    assert evt_b.time() > 0 and np.array(b)[..., 3].max() > 0
+    m.fb.free()
+    with pytest.raises(_lib.FlameError):
+        render.DurationEvent(m.fb, 0).synchronize()           # no context at all: a clean error, no crash
+
+
 def test_default_filter_chain_and_size_changes(mgr):
     """The reference's default chain is bilateral -> logscale -> smearclip (specs.py:107); render it,
     then a different size, then the first size again: buffers are re-sized, walkers / RNG persist, and

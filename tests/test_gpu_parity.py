@@ -26,6 +26,20 @@ def mgr(built):
     return render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
 
 
+@pytest.fixture(scope='module')
+def mgr_prod(built):
+    """The geometry that ships: RenderManager() defaults (1536 slots of 4 waves up to ~1440p)."""
+    m = render.RenderManager(device=0, host_seed=42)
+    assert (m.fb.nw, m.fb.nslots) == render.Framebuffers.NARROW == (4, 1536)
+    return m
+
+
+def walkers(mgr):
+    """(slots, threads per slot, walker count, oracle geometry) of a manager's current context."""
+    ns, nt = mgr.fb.nslots, mgr.fb.nthreads
+    return ns, nt, ns * nt, (O.GEOM_4x64 if nt == 256 else O.GEOM_8x64)
+
+
 def small(cfg, w, h, **kw):
     gnm, prof = cfg(**kw)
     prof = dict(prof, width=w, height=h)
@@ -53,12 +67,15 @@ def test_shuffle_bit_exact(mgr):
         assert np.array_equal(np.sort(out), np.arange(256))
 
 
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg5'])
-def test_interp_params(mgr, cfg):
+@pytest.mark.parametrize('cfg,prod', [('cfg2', False), ('cfg3', False), ('cfg5', False), ('cfg3', True)])
+def test_interp_params(mgr, mgr_prod, cfg, prod):
+    """One parameter block per walker slot (block s at ts + s*td/nslots), for 1024 slots and for
+    the production 1536."""
+    mgr = mgr_prod if prod else mgr
     gnm, prof = small(configs.CONFIGS[cfg], 640, 360)
     rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof, 0.3)
-    F = prepare(gnm, prof, 0.3)
-    dev = mgr.fb.read('params', (1024, rdr.packer.pstride), np.float32, g)
+    F = prepare(gnm, prof, 0.3, nslots=mgr.fb.nslots)
+    dev = mgr.fb.read('params', (mgr.fb.nslots, rdr.packer.pstride), np.float32, g)
     ref = F['params']
     names = ['.'.join(n) for n in rdr.packer.packed]
     lastden = names.index('den.' + rdr.packer.xform_keys[-1])
@@ -74,32 +91,34 @@ def test_interp_params(mgr, cfg):
 def test_palette_bit_exact(mgr):
     gnm, prof = small(configs.cfg3, 640, 360)
     # the palette kernel advances its RNG states: take them from the device first
-    seeds = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
+    ns, nt, nwalk, _ = walkers(mgr)
+    seeds = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)
     rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof, 0.4)
     dev = mgr.fb.read('palette', (64, 256), np.uint64)
     from common import oracle_palette
-    ref, rng_after = oracle_palette(gnm, np.float32(ts), np.float32(td), seeds[NSLOTS * 256:])
+    ref, rng_after = oracle_palette(gnm, np.float32(ts), np.float32(td), seeds[nwalk:])
     assert np.array_equal(dev, ref)
-    seeds2 = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
-    assert np.array_equal(seeds2[NSLOTS * 256:], rng_after)
+    seeds2 = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)
+    assert np.array_equal(seeds2[nwalk:], rng_after)
 
 
-def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1, mode=0, seeds_in=None):
+def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1, mode=0, seeds_in=None, tc=0.5):
     """GPU and oracle from the same device params / palette / seeds / points; returns both states.
     mode 0 = packed global atomics (hot flags + roulette live), 1 = binned (no sample thinning)."""
     lib = _lib.load()
+    ns, nt, nwalk, geom = walkers(mgr)
     if seeds_in is not None:                # before interp: the palette kernel draws from these too
         mgr.fb.write('seeds', seeds_in)
-    seeds0 = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
-    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof)
+    seeds0 = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)
+    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof, tc)
     d = O.calc_dim(dim.w, dim.h)
     nbins = dim.ah * dim.astride
     _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 1))
-    params = mgr.fb.read('params', (1024, rdr.packer.pstride), np.float32, g)
+    params = mgr.fb.read('params', (ns, rdr.packer.pstride), np.float32, g)
     palette = mgr.fb.read('palette', (64, 256), np.uint64)
-    seeds = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)
-    rng = seeds[:NSLOTS * 256].copy()
-    points = np.full((NSLOTS * 256, 4), np.nan, np.float32)
+    seeds = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)
+    rng = seeds[:nwalk].copy()
+    points = np.full((nwalk, 4), np.nan, np.float32)
     hot = np.zeros(nbins // 16, np.uint32)
     atom = np.zeros(nbins, np.uint64)
     out4 = np.zeros((nbins, 4), np.float32)
@@ -108,7 +127,7 @@ def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1, mode=0, seeds_in
     for k in range(launches):
         f = fuse if k == 0 else 0
         _lib.check(lib.fl_debug_iter_launch(mgr.fb.ctx, g, dim.w, dim.h, r0, nrounds + f, f, mode))
-        ctr_ref = O.iter_launch(O.GEOM_4x64, d, rdr.packer.prog, params, palette, rng, points, NSLOTS,
+        ctr_ref = O.iter_launch(geom, d, rdr.packer.prog, params, palette, rng, points, ns,
                                 hot, atom, out4, r0, nrounds + f, f)
         ctr_dev = np.zeros(4, np.uint64)
         _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr_dev.ctypes.data))
@@ -125,8 +144,8 @@ def run_device_model(mgr, gnm, prof, nrounds, fuse, launches=1, mode=0, seeds_in
         res[-1].update(front_dev=mgr.fb.read('front', (nbins, 4), np.float32), front_ref=out4.copy(),
                        hot_dev=mgr.fb.read('hot', (nbins // 16,), np.uint32), hot_ref=hot.copy())
         r0 += nrounds + f
-    dev_rng = mgr.fb.read('seeds', ((NSLOTS + 64) * 256, 3), np.uint32)[:NSLOTS * 256]
-    dev_pts = mgr.fb.read('points', (NSLOTS * 256, 4), np.float32)
+    dev_rng = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)[:nwalk]
+    dev_pts = mgr.fb.read('points', (nwalk, 4), np.float32)
     return res, (rng, points), (dev_rng, dev_pts), dim, seeds0
 
 
@@ -154,6 +173,88 @@ def test_iter_bit_exact_linear(mgr):
         assert np.array_equal(r['hot_dev'], r['hot_ref']), k
     assert np.array_equal(dev_state[0], ref_state[0])          # RNG states after both launches
     assert np.array_equal(dev_state[1][:, :3], ref_state[1][:, :3])
+
+
+def animated_linear_flame():
+    """The transcendental-free flame in motion: camera pan, one rotating xform, two palettes, a
+    frame window that spans the whole animation: every slot sees a different parameter block
+    and the 64 palette rows differ."""
+    gnm, prof = linear_flame()
+    gnm['camera']['center'] = {'x': [-0.15, 0.3, 0.15, 0.3], 'y': 0.0}
+    gnm['camera']['scale'] = 1.0          # zoomed in: every cell stays below the packed-add limit of the binned drain
+    gnm['xforms']['0']['pre_affine']['angle'] = [70.0, 30.0, 100.0, 30.0]
+    gnm['palette'] = [configs._pal(0.0, configs.fire_palette()), configs._pal(1.0, configs.ice_palette())]
+    gnm['time'] = {'duration': 1, 'frame_width': 1.0}
+    return gnm, dict(prof, frame_width=1.0, fps=1, duration=1)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_iter_bit_exact_animated_production_slots(mgr_prod, mode):
+    """Temporal sampling in the geometry that ships (1536 slots): slot s iterates parameter block s
+    and palette row s*64/1536; packed histogram, counters, RNG and walkers equal the oracle's device
+    model, with direct atomics and through the binned accumulate (whose drain kernel derives the
+    palette row of every batch on its own)."""
+    gnm, prof = animated_linear_flame()
+    res, ref_state, dev_state, dim, _ = run_device_model(mgr_prod, gnm, prof, nrounds=19, fuse=5, launches=2, mode=mode)
+    for k, r in enumerate(res):
+        assert int(r['ctr_dev'][3]) == 0 and int(r['ctr_ref'][3]) == 0, 'spill path taken; shrink the test'
+        assert np.array_equal(r['ctr_dev'][:3], r['ctr_ref'][:3]), (k, r['ctr_dev'], r['ctr_ref'])
+        assert np.array_equal(r['atom_dev'], r['atom_ref']), k
+        assert np.array_equal(r['front_dev'], r['front_ref']), k
+    assert np.array_equal(dev_state[0], ref_state[0])
+    assert np.array_equal(dev_state[1][:, :3], ref_state[1][:, :3])
+
+
+def test_temporal_samples_equally_weighted(built):
+    """
+    Every temporal sample of the frame window must receive the same number of iterations (the
+    reference runs one block column per temporal sample: cuburn/render.py:343-346,
+    cuburn/code/iter.py:165,184).  A flame whose only motion is a linear camera pan, rendered by a
+    default RenderManager() at 1920x1080 with the window spanning the whole pan: the density
+    centroid along the pan must sit where the still frame at the window centre has it, and the
+    pan must add the variance of a UNIFORM distribution over the window (T^2/12).  (A 2:1
+    weighting of the window halves, which a 1536-slot geometry gives when slots are mapped onto
+    1024 samples modulo 1024, moves the centroid by T/12 = 5.8 px here and is caught.)
+    """
+    lib = _lib.load()
+    gnm, prof = configs.cfg2(samples=2 ** 26)
+    gnm['camera'] = {'center': {'x': [-0.15, 0.3, 0.15, 0.3], 'y': 0.0}, 'rotation': 0.0, 'scale': 0.12}
+    gnm['time'] = {'duration': 1, 'frame_width': 1.0}
+    still = dict(prof, frame_width=0.0, fps=1, duration=1)
+    moving = dict(prof, frame_width=1.0, fps=1, duration=1)
+    m = render.RenderManager(device=0, host_seed=42)                 # production defaults
+    assert m.fb.nslots == 1536
+    pan_px = 0.3 * 0.12 * 1920
+
+    def moments(prof_):
+        gprof = profile.wrap(prof_, gnm)
+        rdr = render.Renderer(gnm, gprof)
+        dim = m.fb.calc_dim(gprof.width, gprof.height)
+        ts, td = frame_times(gprof, 0.5)
+        g = rdr._handle(m.fb)
+        m._copy(rdr, gnm)
+        _lib.check(lib.fl_interp(m.fb.ctx, g, dim.w, dim.h, ts, td))
+        run = C.c_uint64()
+        _lib.check(lib.fl_iterate(m.fb.ctx, g, dim.w, dim.h, float(2 ** 26), 64, m.resolve_accum_mode(dim), C.byref(run)))
+        front = m.fb.read('front', (dim.ah * dim.astride, 4), np.float32)
+        d = density(front, dim)
+        # central window only: the flame's far tails leave the frame on one side first
+        col = d.sum(0)
+        x = np.arange(dim.astride, dtype=np.float64)
+        mean = (col * x).sum() / col.sum()
+        var = (col * (x - mean) ** 2).sum() / col.sum()
+        return mean, var, td, d.sum() / run.value
+
+    mean_s, var_s, td_s, in_s = moments(still)
+    mean_m, var_m, td_m, in_m = moments(moving)
+    assert td_s == 0 and td_m == 1.0
+    print('centroid still %.3f moving %.3f  variance added %.1f (uniform window: %.1f)  in-frame %.4f %.4f' % (
+        mean_s, mean_m, var_m - var_s, pan_px ** 2 / 12, in_s, in_m))
+    assert in_s > 0.94 and in_m > 0.94, (in_s, in_m)                 # only far tails are clipped
+    assert abs(mean_m - mean_s) < 0.75, (mean_m, mean_s, pan_px / 12)
+    added = var_m - var_s
+    assert abs(added - pan_px ** 2 / 12) < 0.06 * pan_px ** 2 / 12 + 3.0, (added, pan_px ** 2 / 12)
+    m.fb.free()
 
 
 def hot_flame():
@@ -199,8 +300,9 @@ def test_binned_equals_atomic_equals_oracle(mgr, layout, monkeypatch):
     gnm, prof = linear_flame()
     prof = dict(prof, width=1920, height=1080)
     gnm['camera']['scale'] = 1.0          # zoomed in: every cell stays below the 128-hit packed-add limit
-    if layout == 'wide':
+    if layout == 'wide':                  # environment switches are read when a context is created
         monkeypatch.setenv('FLAME_BIN_WIDE', '1')
+        mgr = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
     res_a, ref_a, dev_a, dim, seeds = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=0)
     res_b, ref_b, dev_b, dim, _ = run_device_model(mgr, gnm, prof, nrounds=13, fuse=5, launches=1, mode=1, seeds_in=seeds)
     a, b = res_a[0], res_b[0]
@@ -210,6 +312,8 @@ def test_binned_equals_atomic_equals_oracle(mgr, layout, monkeypatch):
     assert np.array_equal(b['atom_dev'], a['atom_dev'])
     assert np.array_equal(b['front_dev'], a['front_dev'])
     assert np.array_equal(dev_a[0], dev_b[0]) and np.array_equal(dev_a[1][:, :3], dev_b[1][:, :3])
+    if layout == 'wide':
+        mgr.fb.free()
 
 
 @pytest.mark.parametrize('layout', ['narrow', 'wide'])
@@ -218,6 +322,7 @@ def test_binned_hot_region_exact_density(mgr, layout, monkeypatch):
     density must still be exact against the oracle run without hot-pixel thinning."""
     if layout == 'wide':
         monkeypatch.setenv('FLAME_BIN_WIDE', '1')
+        mgr = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
     gnm, prof = hot_flame()
     res, ref_state, dev_state, dim, _ = run_device_model(mgr, gnm, prof, nrounds=40, fuse=16, launches=3, mode=1)
     for k, r in enumerate(res):
@@ -227,6 +332,8 @@ def test_binned_hot_region_exact_density(mgr, layout, monkeypatch):
         assert nd == 0, (k, nd)
         np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=2e-6, atol=1e-4)
     assert np.array_equal(dev_state[0], ref_state[0])
+    if layout == 'wide':
+        mgr.fb.free()
 
 
 def density(front, dim):
@@ -430,10 +537,11 @@ def test_output_bit_exact(mgr, fmt):
     _lib.check(lib.fl_output(mgr.fb.ctx, FW, FH, fmt, out.ctypes.data, 0))
     _lib.check(lib.fl_ctx_sync(mgr.fb.ctx))
     # the dither kernel owns the last 65536 RNG states (walkers | palette rows | output dither)
-    ref, rng_after = O.f32_to_rgba(d, buf, seeds[(NSLOTS + 64) * 256:], fmt)
-    assert len(seeds) - (NSLOTS + 64) * 256 == mgr.fb.nout
+    nwalk = walkers(mgr)[2]
+    ref, rng_after = O.f32_to_rgba(d, buf, seeds[nwalk + 64 * 256:], fmt)
+    assert len(seeds) - (nwalk + 64 * 256) == mgr.fb.nout
     after = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
-    assert np.array_equal(after[(NSLOTS + 64) * 256:], rng_after)
+    assert np.array_equal(after[nwalk + 64 * 256:], rng_after)
     assert np.array_equal(out, ref)
     # cuburn/code/tests/test_output.py ranges: negative -> 0, >1 -> peak
     peak = 65535 if fmt else 255
@@ -461,10 +569,13 @@ def test_queue_frame_end_to_end(mgr):
 
 
 # ---------------------------------------------------------------------------------- larger configs
-def test_cfg3_animated_distribution(mgr):
+@pytest.mark.parametrize('prod', [False, True])
+def test_cfg3_animated_distribution(mgr, mgr_prod, prod):
     """cfg3: 8 xforms + final xform, two interpolated palettes, temporal sampling over the frame
-    window (td > 0: 1024 different parameter blocks, 64 palette rows) against the flam3-style game
-    driven by the oracle's own parameter blocks and palette."""
+    window (td > 0: one parameter block per slot, 64 palette rows) against the flam3-style game
+    driven by the oracle's own parameter blocks and palette — with 1024 slots and with the
+    production 1536."""
+    mgr = mgr_prod if prod else mgr
     gnm, prof = small(configs.cfg3, 480, 270, samples=2 ** 26)
     gprof = profile.wrap(prof, gnm)
     rdr = render.Renderer(gnm, gprof)
@@ -480,7 +591,7 @@ def test_cfg3_animated_distribution(mgr):
     _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 26), 64, 1, C.byref(run)))
     nbins = dim.ah * dim.astride
     front = mgr.fb.read('front', (nbins, 4), np.float32)
-    F = prepare(gnm, prof, tc)
+    F = prepare(gnm, prof, tc, nslots=mgr.fb.nslots)
     ref, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], 2 ** 26, 8)
     dg, dr = density(front, dim), density(ref, dim)
     assert abs(dg.sum() / run.value - dr.sum() / 2 ** 26) < 3e-3
@@ -519,7 +630,7 @@ def run_device_model_gpu_only(mgr, gnm, prof, nrounds, fuse, mode, seeds_in=None
     ctr = np.zeros(4, np.uint64)
     _lib.check(lib.fl_debug_counters(mgr.fb.ctx, ctr.ctypes.data))
     atom = mgr.fb.read('atom', (nbins,), np.uint64)
-    rng = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)[:NSLOTS * 256]
+    rng = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)[:walkers(mgr)[2]]
     return dict(ctr=ctr, atom=atom), None, rng, dim, seeds0
 
 

@@ -3,7 +3,7 @@ Randomised genomes through the C ABI: the structure of the genome is data here (
 interpreter kernel), so parity must hold for ANY structure, not just the BASELINE configs.
 A seeded generator draws xform counts, variation sets (with parameters), post affines, final
 xforms, animated ([p0, v0, p1, v1] + extra knots) splines and two palettes; for each genome:
-  * the 1024 interpolated parameter blocks agree with the oracle's by-name float64 restatement;
+  * the interpolated parameter blocks (one per walker slot) agree with the oracle's by-name float64 restatement;
   * every word of the block that is not a spline / precalc value is exactly the structure the
     program says (variation numbers, counts, zero padding);
   * a short iterate lands the same fraction of samples in frame as the oracle's flam3-style game
@@ -37,6 +37,12 @@ def mgr():
     from __graft_entry__ import build
     build()
     return render.RenderManager(device=0, nslots=NSLOTS, host_seed=23)
+
+
+@pytest.fixture(scope='module')
+def mgr_prod(mgr):
+    """Production geometry (RenderManager() defaults: 1536 slots): used for the animated genomes."""
+    return render.RenderManager(device=0, host_seed=23)
 
 
 def random_spline(rs, lo, hi, animated):
@@ -100,9 +106,12 @@ def random_genome(seed):
 
 
 @pytest.mark.parametrize('seed', list(range(1, 17)))
-def test_random_genome_parity(mgr, seed):
+def test_random_genome_parity(mgr, mgr_prod, seed):
     lib = _lib.load()
     gnm, prof = random_genome(seed)
+    if seed % 2 == 1:                       # animated genomes run in the geometry that ships
+        mgr = mgr_prod
+        assert mgr.fb.nslots == 1536
     gprof = profile.wrap(prof, gnm)
     rdr = render.Renderer(gnm, gprof)
     g = rdr._handle(mgr.fb)
@@ -111,8 +120,8 @@ def test_random_genome_parity(mgr, seed):
     tc = 0.37
     ts, td = frame_times(gprof, tc)
     _lib.check(lib.fl_interp(mgr.fb.ctx, g, dim.w, dim.h, ts, td))
-    dev = mgr.fb.read('params', (1024, rdr.packer.pstride), np.float32, g)
-    F = prepare(gnm, prof, tc)
+    dev = mgr.fb.read('params', (mgr.fb.nslots, rdr.packer.pstride), np.float32, g)
+    F = prepare(gnm, prof, tc, nslots=mgr.fb.nslots)
     ref = F['params']
     names = ['.'.join(n) for n in rdr.packer.packed]
     lastden = names.index('den.' + rdr.packer.xform_keys[-1])

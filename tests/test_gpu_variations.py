@@ -49,7 +49,7 @@ def test_variation_matches_oracle(mgr, name):
     g = rdr._handle(mgr.fb)
     mgr._copy(rdr, gnm)
     _lib.check(lib.fl_interp(mgr.fb.ctx, g, 64, 64, 0.5, 0.0))
-    params = mgr.fb.read('params', (1024, rdr.packer.pstride), np.float32, g)
+    params = mgr.fb.read('params', (mgr.fb.nslots, rdr.packer.pstride), np.float32, g)
 
     rs = np.random.RandomState(V.var_ids[name])
     pts = np.zeros((N, 4), np.float32)

@@ -1,0 +1,196 @@
+// valu_bench.hip — issue-rate micro-benchmark of the instructions the DE filter and the iterate
+// kernel are built from (gfx950).  For each instruction: a wave runs LOOPS x 16 independent
+// copies, brackets them with s_memtime, and the host reports shader cycles per wave-instruction
+// with 1, 2, 4 and 8 waves resident per SIMD (cycles / (instructions x waves per SIMD) is the
+// SIMD's issue cost of one wave-instruction once enough waves hide the dependency latency).
+//   hipcc --offload-arch=gfx950 -O2 -o tools/valu_bench tools/valu_bench.hip && tools/valu_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define LOOPS 512
+
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_bench(uint64_t *out, float seed)
+{
+    __shared__ float lds[4096];
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 256) lds[i] = seed * i;
+    __syncthreads();
+    float a[16];
+    f2 p[16];
+    uint32_t u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = seed + i + tid; p[i] = (f2){seed + i, seed - i}; u[i] = tid * 7 + i; }
+    float b = seed * 0.5f + 1.0f, c = seed * 0.25f;
+    f2 pb = (f2){b, c}, pc = (f2){c, b};
+    const uint32_t addr = (uint32_t)(size_t)lds + (tid & 63) * 4;          // conflict-free b32
+    const uint32_t addr8 = (uint32_t)(size_t)lds + (tid & 63) * 8;         // b64
+    const uint32_t addr16 = (uint32_t)(size_t)lds + (tid & 63) * 16;       // b128
+    float4 q[4];
+    uint64_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = tid + i;
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < LOOPS; ++it) {
+        if (OP == 0) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+            REP16(X)
+#undef X
+        } else if (OP == 1) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(pb), "v"(pc));
+            REP16(X)
+#undef X
+        } else if (OP == 2) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));
+            REP16(X)
+#undef X
+        } else if (OP == 3) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));
+            REP16(X)
+#undef X
+        } else if (OP == 4) {
+#define X(i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == 5) {
+#define X(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == 6) {
+#define X(i) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
+            REP16(X)
+#undef X
+        } else if (OP == 7) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(u[i]), "v"(u[(i + 1) & 15]) : "vcc");
+            REP16(X)
+#undef X
+        } else if (OP == 8) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP16(X)
+#undef X
+        } else if (OP == 9) {
+#define X(i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[i]) : "v"(addr), "n"(i * 256));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 10) {
+#define X(i) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p[i]) : "v"(addr), "n"(i * 4), "n"(i * 4 + 16));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 11) {
+#define X(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p[i]) : "v"(addr8), "n"(i * 512));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 12) {
+#define X(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i & 3]) : "v"(addr16), "n"(i * 1024));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 13) {      // unaligned (4-byte aligned) ds_read_b64: adjacent pixel pairs at odd offsets
+#define X(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(p[i]) : "v"(addr8), "n"(i * 512 + 4));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 14) {      // returning LDS atomic add, conflict-free
+#define X(i) asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3" : "=v"(u[i]) : "v"(addr), "v"(u[(i + 1) & 15]), "n"(i * 256));
+            REP16(X)
+#undef X
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (OP == 15) {
+#define X(i) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == 16) {
+#define X(i) asm volatile("v_sin_f32 %0, %0" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (OP == 17) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+            REP16(X)
+#undef X
+        } else if (OP == 18) {      // packed fma with op_sel mixing halves (same issue cost?)
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p[i]) : "v"(pb), "v"(pc));
+            REP16(X)
+#undef X
+        } else if (OP == 19) {      // dependent chain of v_fma_f32 (latency)
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
+            REP16(X)
+#undef X
+        } else if (OP == 20) {      // s_* scalar ALU issue: 16 s_add_u32 on distinct registers
+            uint32_t s0 = it, s1 = it + 1;
+#define X(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s0) : "s"(s1));
+            REP16(X)
+#undef X
+            u[0] += s0;
+        }
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y + (float)u[i] + (float)w[i];
+    s += q[0].x + q[1].y + q[2].z + q[3].w;
+    if (s == 1.2345e-33f) out[1 << 20] = 1;
+    if ((tid & 63) == 0) out[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int OP>
+static void run(const char *name, uint64_t *d_out, int ncu)
+{
+    printf("%-34s", name);
+    for (int wps : {1, 2, 4, 8}) {              // waves per SIMD = workgroups (4 waves) per CU
+        const int blocks = ncu * wps;
+        hipMemset(d_out, 0, blocks * 4 * 8);
+        hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f);     // warm-up (clocks, i-cache)
+        hipLaunchKernelGGL(k_bench<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f);
+        hipDeviceSynchronize();
+        std::vector<uint64_t> h(blocks * 4);
+        hipMemcpy(h.data(), d_out, blocks * 4 * 8, hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        const double med = (double)h[h.size() / 2];
+        // cycles the SIMD spends per wave-instruction when wps waves share it
+        printf("  wps%d: %6.2f", wps, med / (LOOPS * 16.0) / wps);
+    }
+    printf("   (cycles per wave-instruction per SIMD; wps1 = single-wave issue+latency)\n");
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int ncu = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d kHz\n", prop.gcnArchName, ncu, prop.clockRate);
+    uint64_t *d_out;
+    hipMalloc(&d_out, (1 << 20) * 8 + 64);
+    run<0>("v_fma_f32", d_out, ncu);
+    run<8>("v_mul_f32", d_out, ncu);
+    run<19>("v_fma_f32 dependent chain", d_out, ncu);
+    run<1>("v_pk_fma_f32", d_out, ncu);
+    run<18>("v_pk_fma_f32 op_sel_hi mixed", d_out, ncu);
+    run<2>("v_pk_mul_f32", d_out, ncu);
+    run<3>("v_pk_add_f32", d_out, ncu);
+    run<4>("v_exp_f32", d_out, ncu);
+    run<5>("v_rcp_f32", d_out, ncu);
+    run<16>("v_sin_f32", d_out, ncu);
+    run<6>("v_cmp_gt_f32 + v_cndmask_b32 (2)", d_out, ncu);
+    run<15>("v_rndne_f32", d_out, ncu);
+    run<7>("v_mad_u64_u32", d_out, ncu);
+    run<17>("v_mul_lo_u32", d_out, ncu);
+    run<20>("s_add_u32", d_out, ncu);
+    run<9>("ds_read_b32", d_out, ncu);
+    run<10>("ds_read2_b32", d_out, ncu);
+    run<11>("ds_read_b64", d_out, ncu);
+    run<13>("ds_read_b64 4-byte aligned", d_out, ncu);
+    run<12>("ds_read_b128", d_out, ncu);
+    run<14>("ds_add_rtn_u32", d_out, ncu);
+    hipFree(d_out);
+    return 0;
+}
