@@ -12,7 +12,7 @@ import time
 import traceback
 
 from . import profile
-from .genome import convert, db
+from .genome import convert, store
 
 
 def list_devices():
@@ -24,8 +24,7 @@ def list_devices():
 
 
 def render(args, prof):
-    gdb = db.connect(args.genomedb)
-    gnm, basename = gdb.get_anim(args.flame, args.half)
+    gnm, basename = store.connect(args.genomedb).animation(args.flame, args.half)
     if getattr(args, 'print'):
         print(convert.to_json(gnm))
         return

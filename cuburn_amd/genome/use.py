@@ -78,29 +78,33 @@ class SplineEval(object):
     @staticmethod
     def normalize(knots, scale):
         """
-        Decode a JSON spline into a (2, n) array of knot times / values with the two
-        stabilising end knots at t=-2 and t=3 whose values extend the end velocities
-        (cuburn/genome/use.py:129-158).
+        JSON spline -> (2, n) array [times; values] (cuburn/genome/use.py:129-158).  A number is a
+        constant; ``[a, b]`` runs from a at t=0 to b at t=1 with zero end velocities;
+        ``[p0, v0, p1, v1, t2, p2, ...]`` adds end velocities (per unit of genome time, hence
+        ``scale``) and interior knots.  Guard knots at t=-2 and t=3 make the Catmull-Rom tangent
+        at the first / last real knot equal the requested velocity: each is extrapolated from the
+        knot NEXT to the end knot, which is what a centred difference needs.
         """
-        if isinstance(knots, (int, float, np.number)):
-            v0 = v1 = 0
-            pts = [(0, knots), (1, knots)]
-        elif len(knots) % 2 != 0:
-            raise ValueError("List with odd number of elements given")
-        elif len(knots) == 2:
-            v0 = v1 = 0
-            pts = [(0, knots[0]), (1, knots[1])]
+        if np.isscalar(knots):
+            t, v, vel = np.array([0.0, 1.0]), np.array([knots, knots], dtype=np.float64), (0.0, 0.0)
         else:
-            p0, v0, p1, v1 = knots[:4]
-            pts = [(0, p0), (1, p1)] + list(zip(knots[4::2], knots[5::2]))
-        v0, v1 = v0 * scale, v1 * scale
-        pts = sorted(pts)
-        td = 2
-        if pts[0][0] >= 0:
-            pts = [(-td, pts[1][1] - (pts[1][0] + td) * v0)] + pts
-        if pts[-1][0] <= 1:
-            pts = pts + [(1 + td, pts[-2][1] + (1 + td - pts[-2][0]) * v1)]
-        return np.array(pts, dtype=np.float64).T.copy()
+            flat = np.asarray(knots, dtype=np.float64)
+            if flat.size % 2:
+                raise ValueError("List with odd number of elements given")
+            if flat.size == 2:
+                t, v, vel = np.array([0.0, 1.0]), flat.copy(), (0.0, 0.0)
+            else:
+                t = np.concatenate(([0.0, 1.0], flat[4::2]))
+                v = np.concatenate((flat[[0, 2]], flat[5::2]))
+                vel = (flat[1], flat[3])
+        order = np.lexsort((v, t))                  # by time, ties by value
+        t, v = t[order], v[order]
+        lead, tail = -2.0, 3.0
+        if t[0] >= 0:
+            t, v = np.insert(t, 0, lead), np.insert(v, 0, v[1] - (t[1] - lead) * vel[0] * scale)
+        if t[-1] <= 1:
+            t, v = np.append(t, tail), np.append(v, v[-2] + (tail - t[-2]) * vel[1] * scale)
+        return np.stack([t, v])
 
     def find_knots(self, itime):
         kt, kv = self.knots

@@ -59,21 +59,24 @@ def add_args(parser=None):
 
 
 def get_from_args(args):
-    """Profile dict from parsed arguments; returns ``(name, prof)`` (cuburn/profile.py:76-95)."""
-    if args.profile:
-        name = os.path.basename(args.profile.name).rsplit('.', 1)[0]
-        base = json.load(args.profile)
+    """
+    ``(name, profile dict)`` from parsed arguments (cuburn/profile.py:76-95): a JSON profile file or
+    a builtin as the base, ``--still`` pins one unblurred frame (start 1, end 2, frame_width 0 — which,
+    with enumerate_times below, is frame 2), then every explicitly given option overrides the base.
+    """
+    ns = vars(args)
+    if ns.get('profile'):
+        name = os.path.splitext(os.path.basename(ns['profile'].name))[0]
+        prof = json.load(ns['profile'])
     else:
-        name = args.builtin_profile
-        base = dict(BUILTIN[args.builtin_profile])
-    if args.still:
-        base.update(frame_width=0, start=1, end=2)
-    for arg in _OVERRIDES:
-        if getattr(args, arg, None) is not None:
-            base[arg] = getattr(args, arg)
-    if args.codec is not None:
-        base.setdefault('output', {})['type'] = args.codec
-    return name, base
+        name = ns['builtin_profile']
+        prof = dict(BUILTIN[name])
+    if ns.get('still'):
+        prof['frame_width'], prof['start'], prof['end'] = 0, 1, 2
+    prof.update((k, ns[k]) for k in _OVERRIDES if ns.get(k) is not None)
+    if ns.get('codec') is not None:
+        prof['output'] = dict(prof.get('output') or {}, type=ns['codec'])
+    return name, prof
 
 
 def wrap(prof, gnm):
@@ -83,19 +86,24 @@ def wrap(prof, gnm):
 
 
 def enumerate_times(gprof):
-    """``[(frame_no, [center_times])]`` before/after start, end, skip (cuburn/profile.py:107-127)."""
+    """
+    ``[(frame_no, centre times)]`` of the frames to render (cuburn/profile.py:107-127).  The
+    animation's unit interval is cut into ``round(fps * duration)`` frames; frame k (1-based) is
+    centred on ``(k - 0.5) / nframes``.  With ``shard`` every output holds ``round(fps * shard)``
+    consecutive frames and start / end / skip are ignored.  Otherwise ``end`` keeps frames
+    ``1..end``, ``start`` then drops the first ``start`` of them (so start=1, end=2 — what --still
+    sets — selects frame 2), and every ``skip + 1``-th frame of the rest is rendered.
+    """
     nframes = int(round(gprof.fps * gprof.duration))
-    times = np.linspace(0, 1, nframes + 1)
-    times = times[:-1] + 0.5 * (times[1] - times[0])
+    step = 1.0 / nframes if nframes > 0 else 0.0
+    centres = np.arange(nframes) * step + 0.5 * step
     if gprof.shard:
-        s = max(1, int(round(gprof.fps * gprof.shard)))
-        return [(i, times[t:t + s]) for i, t in enumerate(range(0, len(times), s), 1)]
-    times = list(enumerate([[t] for t in times], 1))
-    if gprof.end is not None:
-        times = times[:gprof.end]
-    if gprof.start is not None:
-        times = times[gprof.start:]
-    return times[::gprof.skip + 1]
+        per_file = max(1, int(round(gprof.fps * gprof.shard)))
+        return [(n + 1, centres[lo:lo + per_file]) for n, lo in enumerate(range(0, nframes, per_file))]
+    first = 0 if gprof.start is None else gprof.start
+    last = nframes if gprof.end is None else gprof.end
+    chosen = list(range(nframes))[:last][first:][::gprof.skip + 1]
+    return [(k + 1, [centres[k]]) for k in chosen]
 
 
 def enumerate_jobs(gprof, basename, args, resume=None):

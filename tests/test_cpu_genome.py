@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from common import REPO
-from cuburn_amd.genome import blend, convert, db, specs, spectypes, util
+from cuburn_amd.genome import blend, convert, store, specs, spectypes, util
 
 GOLD = json.load(open(os.path.join(REPO, 'tests', 'golden', 'genome_front.json')))
 
@@ -106,7 +106,8 @@ def test_convert_affine_identity_and_flip():
 
 @pytest.mark.parametrize('key', sorted(GOLD['anims']))
 def test_node_and_edge_to_anim_match_reference(key):
-    gdb = db.OneFileDB(copy.deepcopy(GOLD['db']))
+    gdb = store.GenomeStore.__new__(store.GenomeStore)
+    gdb.docs, gdb.directory = copy.deepcopy(GOLD['db']), None
     ident, _, mode = key.partition('/')
     doc = gdb.get(ident)
     before = copy.deepcopy(doc)
@@ -166,7 +167,8 @@ def test_sort_xforms_explicit_pairs_and_padding():
 
 
 def test_resolve_unknown_key_is_an_error():
-    gdb = db.OneFileDB({'type': 'onefiledb'})
+    gdb = store.GenomeStore.__new__(store.GenomeStore)
+    gdb.docs, gdb.directory = {}, None
     with pytest.raises(KeyError):
         blend.resolve(gdb, {'type': 'node', 'xforms': {'0': {'chaos': {'0': 1}}}})
 
@@ -175,22 +177,25 @@ def test_db_get_anim_from_files(tmp_path):
     (tmp_path / 'A.json').write_text(json.dumps(GOLD['db']['A']))
     (tmp_path / 'B.json').write_text(json.dumps(GOLD['db']['B']))
     (tmp_path / 'edge1.json').write_text(json.dumps(GOLD['db']['edge1']))
-    gdb = db.connect(str(tmp_path))
-    assert isinstance(gdb, db.FilesystemDB)
-    anim, base = gdb.get_anim('edge1')
+    gdb = store.connect(str(tmp_path))
+    assert gdb.directory == str(tmp_path)
+    anim, base = gdb.animation('edge1')
     assert base == 'edge1'
     approx_equal(anim, GOLD['anims']['edge1'])
-    anim, base = gdb.get_anim('A.json', half=True)
+    anim, base = gdb.animation('A.json', half=True)
     assert base == 'A'
     approx_equal(anim, GOLD['anims']['A/half'])
     flame = tmp_path / 'x.flam3'
     flame.write_text(GOLD['xml']['ref_test'])
-    anim, base = gdb.get_anim(str(flame))
+    anim, base = gdb.animation(str(flame))
     assert base == 'x' and anim['type'] == 'animation'
     approx_equal(anim, GOLD['anims']['X_ref_test/full'])
     one = tmp_path / 'all.json'
     one.write_text(json.dumps(GOLD['db']))
-    assert isinstance(db.connect(str(one)), db.OneFileDB)
+    onefile = store.connect(str(one))
+    assert onefile.directory is None and onefile.get('B')['name'] == 'B'
+    with pytest.raises(KeyError):
+        onefile.get('nope')
     gdb.stash('tmp', GOLD['db']['B'])
     assert gdb.get('tmp')['name'] == 'B'
 

@@ -718,15 +718,15 @@ def test_sample_sharded_frame_two_virtual_ranks(built):
 
 
 def test_flam3_xml_to_frame(mgr, tmp_path):
-    """Front end to pixels: flam3 XML -> node -> looping animation (genome.db.get_anim) -> queue_frame."""
+    """Front end to pixels: flam3 XML -> node -> looping animation (genome.store) -> queue_frame."""
     import json
-    from cuburn_amd.genome import db
+    from cuburn_amd.genome import store
     gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
     src = gold['xml']['rich'].replace(' chaos="1 0.5 2"', '')
     path = tmp_path / 'rich.flam3'
     path.write_text(src)
     with pytest.warns(UserWarning):
-        gnm, base = db.connect(str(tmp_path)).get_anim(str(path))      # two flames in the file: first is used
+        gnm, base = store.connect(str(tmp_path)).animation(str(path))      # two flames in the file: first is used
     assert base == 'rich' and gnm['type'] == 'animation'
     prof = dict(configs.cfg2()[1], width=320, height=240)
     gprof = profile.wrap(prof, gnm)
