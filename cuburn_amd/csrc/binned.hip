@@ -58,11 +58,14 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifndef ACC_ILP
 #define ACC_ILP 4
 #endif
+#ifndef ACC_THREADS
+#define ACC_THREADS 1024        /* threads per accumulate workgroup (narrow tiles) */
+#endif
 
 // TWL: log2 of the tile width (7: 128x64 tiles = 64 KB of LDS cells, two workgroups per CU;
 // 8: 256x64 tiles = 128 KB, for images with more than 2047 narrow tiles)
 template <uint32_t TWL>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024)
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
@@ -182,6 +185,6 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
     }
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
-    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(1024), FL_TILE_CELLS * 8 + 1024 * 4, st, log, dir, palette, atom, out4,
+    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4, st, log, dir, palette, atom, out4,
                        tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
 }

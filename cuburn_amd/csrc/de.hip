@@ -1,0 +1,462 @@
+// de.hip — one direction of the density-estimation filter as ONE kernel (gfx950).
+//
+// The reference runs, per direction, den_blur -> den_blur_1c -> bilateral through textures
+// (cuburn/filters.py:62-95; cuburn/code/filters.py:106-131,166-264).  The first MI355X form
+// (filters.hip: k_den_blur2_lds + k_de_bilateral_pk) kept that split and moved three per-pixel
+// planes between the two kernels.  Here a direction reads the normalised image N = (x/w, y/w, z/w, w)
+// once and writes it once; everything else lives in LDS for the lifetime of a tile:
+//
+//   * Sheared tiles.  Row j of a tile (and of its halo) starts S(j) = floor(j*K/2) pixels further
+//     right, K/2 being the direction's x step per row, so that every tap of a pixel, every tap of
+//     the two density blurs at a tap, and their neighbours land in (almost) the same COLUMN of the
+//     staged parallelogram: the halo is 24 rows (13 for the directions that advance two pixels per
+//     row) by 0..2 columns.  The horizontal direction uses 8 x 128 tiles with a 24-column halo.
+//   * Both density blurs (7 taps at step 1, 7 taps at step 2) are evaluated in LDS for every staged
+//     position a tap can reach, in the reference's summation order.
+//   * The gradient factor exp2(-exp2(+-gspeed * (next.w - prev.w) / (avg + 1e-6))) of a tap
+//     depends on the tap POSITION and the sign of r only (cuburn/code/filters.py:241-245) — for
+//     the four directions with integer steps.  There the inner exponentials are two per-pixel
+//     planes H+ / H- computed once per staged pixel, and the 31-tap loop keeps ONE v_exp_f32 per
+//     tap.  For the half-slope directions next / prev depend on r mod 4 (the tap offsets are
+//     rounded), so the inner exponential stays in the loop (two v_exp_f32 per tap).
+//   * w^dpow is computed when a pixel is staged (2 transcendentals per staged pixel instead of a
+//     4-byte plane read and written per direction).
+//   * The kernel is VALU-bound (SQ counters: vector ALU busy > 80 %, ~4.3 cycles per wave
+//     instruction), so the tap arithmetic is arranged for the fewest instructions.  The colour
+//     distance |n_q - c|^2 is expanded: cs*|n_q|^2 is a per-pixel plane S, -2*cs*c a per-centre
+//     vector C', and cs*|c|^2 — common to every tap of a centre — is factored out of the loop
+//     altogether (all five sums scale by 2^(cs*|c|^2), which is undone once at the end):
+//         e = S_q + n_q . C'   (3 fma; "dead" tap or centre: a select to cs/2 - cs*|c|^2)
+//           - | |ds|*pw_c - |ds|*pw_q |  - H(q)          (|ds|*w^dpow is a per-pixel plane too)
+//     12 -> 8 instructions in front of the exponential.
+//   * Image edges.  The reference clamps every texture fetch (cuburn/code/filters.py:22-35), which
+//     makes the blurred density at a tap outside the image the blur AT the clamped position, not
+//     the blur of the clamped image.  Staged positions outside the image (they exist only in
+//     border tiles) get their two blur values from a direct evaluation on the global image.
+//
+// Scalar (non-packed) math: on gfx950 v_pk_fma_f32 issues at ~1.6x the cost of v_fma_f32
+// (tools/valu_bench.hip), which does not pay for the 16-apart pixel pairing and ds_read2_b32
+// traffic the packed form needs; 1024-thread workgroups at <= 64 VGPRs keep 8 waves per SIMD.
+#include "flame_device.h"
+#include "kernels.h"
+#include <utility>
+#include <cmath>
+
+struct DeCoefs { float k[7]; };
+struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
+
+// ---- compile-time geometry of a direction --------------------------------------------------
+// cuburn/code/filters.py:8-17,26-34: tap offset = round-to-nearest-even of slope * r
+__host__ __device__ constexpr int de_num_x(int P) { constexpr int n[8] = {2, 0, 2, -2, 2, -1, 2, 1}; return n[P]; }
+__host__ __device__ constexpr int de_num_y(int P) { constexpr int n[8] = {0, 2, 2, 2, 1, 2, -1, 2}; return n[P]; }
+__host__ __device__ constexpr int de_rne_half(int v)      // v / 2 rounded to nearest, ties to even
+{
+    return (v % 2 == 0) ? v / 2 : ((v - 1) / 2 % 2 == 0 ? (v - 1) / 2 : (v + 1) / 2);
+}
+__host__ __device__ constexpr int de_dx(int P, int r) { return de_rne_half(de_num_x(P) * r); }
+__host__ __device__ constexpr int de_dy(int P, int r) { return de_rne_half(de_num_y(P) * r); }
+// shear: x shift of tile row j = floor(j * K / 2)
+__host__ __device__ constexpr int de_k(int P) { constexpr int k[8] = {0, 0, 2, -2, 4, -1, -4, 1}; return k[P]; }
+__host__ __device__ constexpr int de_floor_half(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
+__host__ __device__ constexpr int de_shear(int P, int j) { return de_floor_half(j * de_k(P)); }
+// column displacement in sheared coordinates of an image displacement (dx, dy) from a row of parity par
+__host__ __device__ constexpr int de_dv(int P, int par, int dx, int dy)
+{
+    return dx - (de_shear(P, par + dy) - de_shear(P, par));
+}
+__host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // integer steps: H+ / H- planes
+
+#ifndef DE_TW_
+#define DE_TW_ 32      /* 16 (64-row tiles, staged / output 1.75 instead of 2.5) measured 10-25 % slower: ragged band ends, 256-byte row segments */
+#endif
+struct DeReach { int hu, hv; };
+// Largest row / column displacement (sheared coordinates) of any staged value a tile pixel needs:
+// tap r, then the second blur's tap 2i there, then the first blur's tap j there (each offset is
+// rounded on its own, as the reference's nested clamped fetches are).  blur = false: taps only.
+__host__ __device__ constexpr DeReach de_reach(int P, bool blur)
+{
+    int hu = 0, hv = 0;
+    for (int par = 0; par < 2; ++par)
+        for (int r = -16; r <= 16; ++r)
+            for (int i = -3; i <= 3; ++i)
+                for (int j = -3; j <= 3; ++j) {
+                    if (!blur && (i != 0 || j != 0 || r == 16 || r == -16)) continue;
+                    if ((r == 16 || r == -16) && (i != 0 || j != 0 || de_hoisted(P))) continue;   // +-16: next / prev density only
+                    int u = de_dy(P, r), v = de_dv(P, par, de_dx(P, r), de_dy(P, r));
+                    int p1 = (par + u) & 1;
+                    v += de_dv(P, p1, de_dx(P, 2 * i), de_dy(P, 2 * i)); u += de_dy(P, 2 * i);
+                    int p2 = (par + u) & 1;
+                    v += de_dv(P, p2, de_dx(P, j), de_dy(P, j)); u += de_dy(P, j);
+                    hu = (u < 0 ? -u : u) > hu ? (u < 0 ? -u : u) : hu;
+                    hv = (v < 0 ? -v : v) > hv ? (v < 0 ? -v : v) : hv;
+                }
+    return DeReach{hu, hv};
+}
+
+template <int P> struct DeGeo {
+    static constexpr int K = de_k(P);
+    // output tile (1024 pixels)
+    static constexpr int TW = P == 0 ? 128 : DE_TW_, TH = P == 0 ? 8 : 1024 / DE_TW_;
+    static constexpr bool HOIST = de_hoisted(P);
+    // plane A (normalised pixels): everything a tile pixel's taps and their blurs can reach
+    static constexpr int HU = de_reach(P, true).hu, HV = de_reach(P, true).hv;
+    static constexpr int ROWS = TH + 2 * HU, COLS = TW + 2 * HV, NPX = ROWS * COLS;
+    static constexpr int NIT = (NPX + 1023) / 1024;
+    // plane B (per-pixel tap terms): the positions of the taps themselves
+    static constexpr int HBU = de_reach(P, false).hu, HBV = de_reach(P, false).hv;
+    static constexpr int BROWS = TH + 2 * HBU, BCOLS = TW + 2 * HBV, NPXB = BROWS * BCOLS;
+    static constexpr int NITB = (NPXB + 1023) / 1024;
+    // LDS: A float4[NPX] | B float4[NPXB]; the preparation's two dense float planes live in B's space
+    static constexpr size_t LDS = (size_t)(NPX + NPXB) * 16 + 64;
+    static constexpr int SPAN = de_shear(P, TH - 1) < 0 ? -de_shear(P, TH - 1) : de_shear(P, TH - 1);
+    // element offset of image displacement (dx, dy) from a position in a row of parity par
+    static constexpr int off(int par, int dx, int dy) { return dy * COLS + de_dv(P, par, dx, dy); }
+    static constexpr int offb(int par, int dx, int dy) { return dy * BCOLS + de_dv(P, par, dx, dy); }
+    static constexpr int tap_off(int par, int r) { return off(par, de_dx(P, r), de_dy(P, r)); }
+    static constexpr int tap_offb(int par, int r) { return offb(par, de_dx(P, r), de_dy(P, r)); }
+    static constexpr int min_tap_off(int par)
+    {
+        int m = 0;
+        for (int r = -16; r <= 16; ++r) m = tap_off(par, r) < m ? tap_off(par, r) : m;
+        return m;
+    }
+    static constexpr int min_tap_offb(int par)
+    {
+        int m = 0;
+        for (int r = -15; r <= 15; ++r) m = tap_offb(par, r) < m ? tap_offb(par, r) : m;
+        return m;
+    }
+};
+
+__device__ __forceinline__ int de_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// Direct evaluation of the two density blurs at an in-image position (border tiles only)
+template <int P>
+__device__ float de_b1_global(const float4 *__restrict__ N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
+{
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int x = de_clampi(cx + de_dx(P, j - 3), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, j - 3), 0, (int)d.ah - 1);
+        den += N[(uint32_t)(y * (int)d.astride + x)].w * k.k[j];
+    }
+    return den;
+}
+template <int P>
+__device__ float de_b2_global(const float4 *__restrict__ N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
+{
+    float den = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 7; ++i) {
+        const int x = de_clampi(cx + de_dx(P, 2 * (i - 3)), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, 2 * (i - 3)), 0, (int)d.ah - 1);
+        den += de_b1_global<P>(N, d, x, y, k) * k.k[i];
+    }
+    return den;
+}
+
+// The 31-tap loop of one output pixel.  PAR = parity of the pixel's tile row (matters for odd K).
+//
+// Left to itself the compiler either hoists all LDS reads of the unrolled loop or sinks the
+// five accumulation chains below them (700 bytes of scratch per lane either way), so the reads
+// are explicit ds_read asm with immediate offsets from one base address per plane, in a
+// two-taps-per-step, double-buffered software pipeline: step g issues the reads of step g+1,
+// then waits (s_waitcnt lgkmcnt(n), n = the reads just issued) for its own.  The waiting asm
+// takes the step's buffer AND the accumulators as read-write operands: that is what pins the
+// arithmetic of step g-1 before it and the arithmetic of step g after it.
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct DeTap { f4v a, b; };         // A at tap r+1 (the next pixel), B at tap r = (|ds|*w^dpow, cs*|n|^2, H+ | g/(avg+1e-6), H-)
+
+#define DE_RD128(dst, addr, boff) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(boff) : "memory")
+
+template <int P> __host__ __device__ constexpr int de_tap_reads(int r)       // LDS reads issued for tap r
+{
+    if (r > 15) return 0;
+    return ((r < 15 || !de_hoisted(P)) ? 1 : 0) + 1;
+}
+
+template <int P, int PAR>
+__device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const float4 *__restrict__ sB, int ci, int cb,
+                                            float cs2, const DeSpatial &spk, float4 &res)
+{
+    using G = DeGeo<P>;
+    constexpr int MINOFF = G::min_tap_off(PAR), MINOFFB = G::min_tap_offb(PAR);
+#define TOFF(r) (G::tap_off(PAR, (r)) - MINOFF)
+#define TOFFB(r) (G::tap_offb(PAR, (r)) - MINOFFB)
+    static_assert((G::tap_off(PAR, 16) - MINOFF) * 16 < 65536 && (G::tap_off(PAR, -16) - MINOFF) >= 0, "tap offsets must fit the DS immediate");
+    const float4 *__restrict__ bA = sA + (ci + MINOFF);
+    const float4 *__restrict__ bB = sB + (cb + MINOFFB);
+    // LDS byte addresses of the two planes' bases (dynamic LDS starts at the kernel's LDS base)
+    uint32_t aA = (uint32_t)(size_t)bA, aB = (uint32_t)(size_t)bB;
+    const float4 cen = bA[TOFF(0)];
+    // the reference normalises the centre with 1/(w + 1e-6) and the taps with 1/w
+    const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
+    const float ccx = cen.x * cfix, ccy = cen.y * cfix, ccz = cen.z * cfix;
+    const bool cen_live = cen.w > 0.0f;
+    // cs*|n_q - c|^2 = S_q + n_q . C' + cs*|c|^2; the last term is the same for every tap of this
+    // centre and stays outside the loop (see the end).  A dead tap or a dead centre makes the colour
+    // difference 0.5: select cs/2 (minus the factored term).
+    const float m2 = -2.0f * cs2;
+    float Cx = ccx * m2, Cy = ccy * m2, Cz = ccz * m2;
+    const float biasp = cen_live ? cs2 * fmaf(ccz, ccz, fmaf(ccy, ccy, ccx * ccx)) : 0.0f;
+    float thr = cen_live ? 0.0f : __builtin_inff();           // tap live <=> w_q > thr
+    float Kp = 0.5f * cs2 - biasp;
+    float cds = bB[TOFFB(0)].x;                               // |ds| * w_c^dpow
+    float wprev = G::HOIST ? 0.0f : bA[TOFF(-16)].w;
+    const float4 p0 = bA[TOFF(-15)];
+    f4v pix = {p0.x, p0.y, p0.z, p0.w};
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, ow = 0.0f, wsum = 0.0f;
+
+    DeTap L[2][2];
+    auto issue = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+#define ISSUE_TAP(k) if constexpr (-15 + g * 2 + (k) <= 15) { \
+            constexpr int r = -15 + g * 2 + (k); \
+            if constexpr (r < 15 || !G::HOIST) DE_RD128(L[g & 1][k].a, aA, TOFF(r + 1) * 16); \
+            DE_RD128(L[g & 1][k].b, aB, TOFFB(r) * 16); }
+        ISSUE_TAP(0) ISSUE_TAP(1)
+#undef ISSUE_TAP
+    };
+    auto step = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
+        constexpr int inflight = g + 1 < 16 ? de_tap_reads<P>(-15 + (g + 1) * 2) + de_tap_reads<P>(-14 + (g + 1) * 2) : 0;
+        DeTap (&T)[2] = L[g & 1];
+        asm volatile("s_waitcnt lgkmcnt(%19)"
+                     : "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b),
+                       "+v"(aA), "+v"(aB), "+v"(ox), "+v"(oy), "+v"(oz), "+v"(ow), "+v"(wsum),
+                       "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(thr), "+v"(Kp), "+v"(cds)
+                     : "n"(inflight));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = -15 + g * 2 + k;
+            if (r <= 15) {
+                float t = fmaf(pix.x, Cx, fmaf(pix.y, Cy, fmaf(pix.z, Cz, T[k].b.y)));
+                t = pix.w > thr ? t : Kp;
+                float e = t - fabsf(cds - T[k].b.x);
+                if (r != 0) {
+                    if (G::HOIST) e -= r < 0 ? T[k].b.w : T[k].b.z;
+                    else {
+                        const float gr = (T[k].a.w - wprev) * T[k].b.z;          // b.z = gspeed / (avg + 1e-6)
+                        e -= fexp2(r < 0 ? -gr : gr);
+                    }
+                }
+                const float factor = spk.s[r < 0 ? -r : r] * fexp2(e);
+                wsum += factor;
+                const float fw = factor * pix.w;
+                ox = fmaf(fw, pix.x, ox); oy = fmaf(fw, pix.y, oy); oz = fmaf(fw, pix.z, oz); ow += fw;
+                wprev = pix.w;
+                if (r < 15 || !G::HOIST) pix = T[k].a;
+            }
+        }
+    };
+    issue(std::integral_constant<int, 0>{});
+    [&]<int... Gs>(std::integer_sequence<int, Gs...>) __attribute__((always_inline)) {
+        (step(std::integral_constant<int, Gs>{}), ...);
+    }(std::make_integer_sequence<int, 16>{});
+#undef TOFF
+#undef TOFFB
+    // undo the factored 2^(cs*|c|^2): out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is
+    // their ratio (the 1/weightsum of the reference cancels, and so does the factor), the density
+    // is out.w / (weightsum + 1e-10)
+    const float Bf = fexp2(biasp);
+    const float tw = ow * Bf;
+    const float wn = tw * frcp(fmaf(wsum, Bf, 1e-10f));
+    const float rn = tw >= 1.17549435e-38f ? frcp(ow) : 0.0f;   // v_rcp_f32 of a denormal is +inf
+    res = make_float4(ox * rn, oy * rn, oz * rn, wn);
+}
+
+template <int P>
+__global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
+k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
+         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles)
+{
+    using G = DeGeo<P>;
+    static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *sA = reinterpret_cast<float4 *>(smem);
+    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPX * 16);
+    float *sW = reinterpret_cast<float *>(sB);                   // prep: dense density plane ...
+    float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of
+    // tiles in column-major order, so that the tiles resident together on an XCD are vertical
+    // neighbours and find each other's halo rows in that XCD's L2.
+    const uint32_t per_xcd = (ntiles + 7u) / 8u;
+    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
+    const int tx = (int)(t / tiles_y), ty = (int)(t % tiles_y);
+    // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
+    const int bx0 = tx * G::TW - (G::K > 0 ? G::SPAN : 0), by0 = ty * G::TH;
+    const int tid = threadIdx.x;
+    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
+    // does any staged position leave the image?  (block-uniform)
+    const bool border = by0 - G::HU < 0 || by0 + G::TH + G::HU > (int)d.ah ||
+                        bx0 + min(0, de_shear(P, -G::HU)) + min(0, de_shear(P, G::TH + G::HU)) - G::HV - 1 < 0 ||
+                        bx0 + max(0, de_shear(P, -G::HU)) + max(0, de_shear(P, G::TH + G::HU)) + G::TW + G::HV + 1 > (int)d.astride;
+
+    // ---- S0: stage N (edge-clamped) and the dense density plane ------------------------------
+    float4 tn[G::NIT];
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int idx = min(it * 1024 + tid, G::NPX - 1);
+        const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
+        const int gx = de_clampi(bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, 0, xmax);
+        const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
+        tn[it] = N[(uint32_t)(gy * (int)d.astride + gx)];
+    }
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int idx = it * 1024 + tid;
+        if (idx < G::NPX) { sA[idx] = tn[it]; sW[idx] = tn[it].w; }
+    }
+    __syncthreads();
+
+    // ---- S1: first density blur (7 taps, step 1) ----------------------------------------------
+    // Every staged position is evaluated; where a tap leaves the staged region it reads whatever
+    // lies next to the plane inside this workgroup's LDS (plane A below, the blur plane above) and
+    // the value is meaningless — by construction of the halo (de_reach) no tile pixel ever needs it.
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+        const int idx = it * 1024 + tid;
+        if (idx >= G::NPX) continue;
+        const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
+        const bool par = ((ul - G::HU) & 1) != 0;
+        float den = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int o0 = G::off(0, de_dx(P, j - 3), de_dy(P, j - 3)), o1 = G::off(1, de_dx(P, j - 3), de_dy(P, j - 3));
+            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
+            den = fmaf(sW[idx + o], kc.k[j], den);
+        }
+        if (border) {
+            const int gxu = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gyu = by0 + ul - G::HU;
+            if (gxu < 0 || gxu > xmax || gyu < 0 || gyu > ymax)         // virtual position: the blur AT the clamped position
+                den = de_b1_global<P>(N, d, de_clampi(gxu, 0, xmax), de_clampi(gyu, 0, ymax), kc);
+        }
+        s1[idx] = den;
+    }
+    __syncthreads();
+
+    // ---- S2: per-pixel tap terms for every position a tap can land on -------------------------
+    // second blur (7 taps, step 2) -> gspeed / (avg + 1e-6) -> gradient exponentials; |ds| * w^dpow;
+    // cs * |n|^2.  Held in registers until every thread is done with the preparation planes.
+    float4 pb[G::NITB];
+#pragma unroll
+    for (int it = 0; it < G::NITB; ++it) {
+        const int bidx = it * 1024 + tid;
+        pb[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (bidx >= G::NPXB) continue;
+        const int ub = bidx / G::BCOLS, vb = bidx - ub * G::BCOLS;
+        const int ul = ub + G::HU - G::HBU, vl = vb + G::HV - G::HBV;
+        const int idx = ul * G::COLS + vl;
+        const bool par = ((ul - G::HU) & 1) != 0;
+        float den = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int o0 = G::off(0, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3))), o1 = G::off(1, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3)));
+            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
+            den = fmaf(s1[idx + o], kc.k[i], den);
+        }
+        if (border) {
+            const int gxu = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gyu = by0 + ul - G::HU;
+            if (gxu < 0 || gxu > xmax || gyu < 0 || gyu > ymax)
+                den = de_b2_global<P>(N, d, de_clampi(gxu, 0, xmax), de_clampi(gyu, 0, ymax), kc);
+        }
+        const float ra = frcp(den + 1.0e-6f) * gspeed;
+        const float4 n = sA[idx];
+        pb[it].x = ads * fpow(n.w, dpow);
+        pb[it].y = cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x));
+        if (G::HOIST) {
+            // next / prev of a tap at this position are its neighbours one step along the direction
+            // (integer steps: t(r+1) - t(r) = t(1) for every r); staged values are edge-clamped, so
+            // this is next.w - prev.w of the reference for virtual positions as well
+            constexpr int dn = G::off(0, de_dx(P, 1), de_dy(P, 1));
+            const float g = (sW[idx + dn] - sW[idx - dn]) * ra;
+            pb[it].z = fexp2(g);
+            pb[it].w = fexp2(-g);
+        } else {
+            pb[it].z = ra;
+        }
+    }
+    __syncthreads();
+    // ---- S3: the per-pixel plane replaces the preparation planes -------------------------------
+#pragma unroll
+    for (int it = 0; it < G::NITB; ++it) {
+        const int bidx = it * 1024 + tid;
+        if (bidx < G::NPXB) sB[bidx] = pb[it];
+    }
+    __syncthreads();
+
+    // ---- taps --------------------------------------------------------------------------------
+    // thread -> output pixel: a wave covers two rows of equal parity (row parity selects the tap
+    // offsets when K is odd); the horizontal direction: 64 consecutive pixels of one row
+    const int wv = tid >> 6, lane = tid & 63;
+    int ou, ov;
+    if (P == 0) { ou = wv >> 1; ov = (wv & 1) * 64 + lane; }
+    else {
+        constexpr int RPW = 64 / G::TW;                                   // rows per wave (equal parity)
+        ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW); ov = lane % G::TW;
+    }
+    const int ci = (ou + G::HU) * G::COLS + ov + G::HV;
+    const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
+    float4 res;
+    if ((G::K & 1) && (wv & 1)) de_tap_loop<P, 1>(sA, sB, ci, cb, cs2, spk, res);
+    else de_tap_loop<P, 0>(sA, sB, ci, cb, cs2, spk, res);
+
+    const int xo = bx0 + ((ou * G::K) >> 1) + ov, yo = by0 + ou;
+    if (xo >= 0 && xo <= xmax && yo <= ymax)                        // the parallelogram sticks out of the image at both ends of a band
+        Nout[(uint32_t)(yo * (int)d.astride + xo)] = res;
+}
+
+// Normalise the accumulator into N (first pass input); with YUV -> RGB in front when the chain starts with `yuv`
+__device__ __forceinline__ float4 de_yuv_px(float4 p)       // cuburn/code/filters.py:71-77 + cuburn/code/color.py:25-40
+{
+    const float u = p.y - 0.5f * p.w, v = p.z - 0.5f * p.w;
+    return make_float4(fmaxf(0.0f, p.x + 1.402f * v), fmaxf(0.0f, p.x - 0.34414f * u - 0.71414f * v), fmaxf(0.0f, p.x + 1.772f * u), p.w);
+}
+template <bool YUV>
+__global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__restrict__ N, const float4 *__restrict__ src)
+{
+    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi >= n) return;
+    float4 p = src[gi];
+    if (YUV) p = de_yuv_px(p);
+    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
+    N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
+}
+
+template <int P>
+static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
+                              float cs2, float ads, float dpow, float gspeed)
+{
+    using G = DeGeo<P>;
+    static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
+    static unsigned long long attr = 0;
+    ensure_max_dynamic_lds((const void *)k_de_dir<P>, attr);
+    const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
+    const uint32_t ntiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(k_de_dir<P>, dim3(8 * ((ntiles + 7) / 8)), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
+                       cs2, ads, dpow, gspeed, tiles_y, ntiles);
+}
+
+void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
+                   float sstd, float cstd, float dstd, float dpow, float gspeed)
+{
+    DeCoefs kc;
+    for (int i = 0; i < 7; ++i) kc.k[i] = coefs7[i];
+    // per-launch scalars (cuburn/code/filters.py:176-183), evaluated once on the host
+    DeSpatial spk;
+    for (int r = 0; r < 16; ++r) spk.s[r] = expf((float)(r * r) / (-1.41421353816986f * sstd));
+    const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
+    const float ads = fabsf(-0.5f / dstd);
+#define DE(P) case P: launch_de_dir_one<P>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed); break
+    switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
+#undef DE
+}
+
+void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv)
+{
+    const uint32_t n = d.ah * d.astride;
+    if (yuv) hipLaunchKernelGGL(k_de_normalise<true>, dim3((n + 255) / 256), dim3(256), 0, st, n, N, src);
+    else hipLaunchKernelGGL(k_de_normalise<false>, dim3((n + 255) / 256), dim3(256), 0, st, n, N, src);
+}

@@ -79,7 +79,7 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    bool env_bin_wide = false, env_de_reference = false, env_de_gather = false, env_de_aos = false;
+    bool env_bin_wide = false, env_de_reference = false, env_de_gather = false, env_de_aos = false, env_de_split = false;
 };
 #define L(c) ((c)->lanes[(c)->cur])
 #define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
@@ -218,6 +218,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     c->env_de_gather = env_on("FLAME_DE_GATHER");
     c->env_de_aos = env_on("FLAME_DE_LDS_AOS");
+    c->env_de_split = env_on("FLAME_DE_SPLIT") || c->env_de_aos;      // previous form: blur kernel + bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
     // every failure below leaves through fl_ctx_destroy, which frees whatever exists so far
@@ -644,6 +645,18 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
                 launch_bilateral(st, d, L(c).d_back, L(c).d_front, (const float *)L(c).d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(L(c).d_front, L(c).d_back);
             }
+            break;
+        }
+        if (!c->env_de_gather && !c->env_de_split) {
+            // One kernel per direction (de.hip): N ping-pongs between the back and front buffers
+            float4 *Na = L(c).d_back, *Nb = L(c).d_front;
+            launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
+            L(c).pend_yuv = false;
+            for (int pat = 0; pat < 8; ++pat) {
+                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
+                std::swap(Na, Nb);
+            }
+            L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
             break;
         }
         if (!c->env_de_gather) {

@@ -70,5 +70,10 @@ void launch_haloclip(hipStream_t st, fl_dim d, float4 *buf, const float *den, fl
 void launch_plainclip(hipStream_t st, fl_dim d, float4 *buf, float gam_m_1, float lin, float lingam, float brightness);
 void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, float degamma);
 
+// de.hip
+void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
+                   float sstd, float cstd, float dstd, float dpow, float gspeed);
+void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv);
+
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);
