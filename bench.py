@@ -7,25 +7,38 @@ bench.py — headline benchmark of the flame hot path on MI355X.
 
 A step = one full frame of BASELINE.json configs[1] ("cfg2": 1920x1080 still, 3 xforms
 linear + spherical + swirl, 2^28 samples) through the drop-in entry point
-RenderManager.queue_frame: parameter interpolation, chaos-game iteration + flush, the filter
-chain (yuv -> bilateral DE -> logscale -> colorclip) and output conversion.  Frames are
-independent, so with N GPUs every rank renders its own frames (weak scaling, no collective
-in the data path) and the finished 8-bit frames are gathered to rank 0 over RCCL.
+RenderManager.queue_frame: parameter interpolation, chaos-game iteration + tile accumulate +
+flush, the filter chain (yuv -> bilateral DE -> logscale -> colorclip) and output conversion.
+Frames are independent, so with N GPUs every rank renders its own frames (weak scaling, no
+collective in the data path); the finished 8-bit frames go straight from fl_output into device
+tensors that RCCL gathers to rank 0, four frames per collective, asynchronously.
+
+Order of work: the CPU baseline FIRST (so that GPU activity is contiguous afterwards), then
+preheat, W warm-up steps, K timed steps (barrier + synchronize on both sides, max over ranks),
+then the kernel-level section on a one-lane context.
 
 Prints ONE JSON line on rank 0:
-  value     = write-enabled chaos-game samples per second, whole job (Msamples/s)
-  roofline  = dominant kernel (k_iter): algorithmic 16 B/sample (the 8-byte
-              read-modify-write of the packed cell) x samples per launch / HIP-event launch time,
-              vs the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from the TCC counters
-              (profiles/r01_pmc_traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-              passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  `pipeline` is the same
-              figure over the whole iterate+accumulate chain (k_iter + k_accum_tiles + k_flush).
-  cpu_baseline = the oracle's flam3-style chaos game on the host cores (rank 0, N=1 only)
+  value     = write-enabled chaos-game samples per second, whole job (Msamples/s), fuse 64
+  config.fuse_reference = the same loop with the reference's fuse of 256 (cuburn/render.py:215)
+  roofline  = the iterate CHAIN (k_iter + k_accum_tiles + k_flush — the kernels that together perform
+              the 8-byte read-modify-write per sample that SURVEY.md §8d's 16 B/sample stand for):
+              16 B x samples / HIP-event time of those kernels, vs the 8 TB/s HBM peak.  `traffic` =
+              HBM bytes of the chain per frame from the TCC counters (profiles/r02_pmc_traffic.json:
+              rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per
+              MI355X_MICROARCH.md §HBM).  `k_iter` carries that kernel's own launch time and its
+              MEASURED bytes (it writes 4-byte log records, not the packed cells).
+  de_filter = the DE proper (normalise + 8 direction kernels + un-normalise): 512 B/px algorithmic
+              over its own HIP-event time, vs 8 TB/s and vs the copy bandwidth measured here.
+  cpu_baseline = the oracle's flam3-style chaos game built -O3 -march=native on this host,
+              T = 1 and T = all usable cores (rank 0, N = 1 only)
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -48,23 +61,69 @@ def usable_cores():
     return n
 
 
+def native_oracle():
+    """the CPU baseline is built -O3 -march=native for the host it runs on.  The
+    portable oracle/libflame_ref.so (x86-64-v3, what the tests use) is the fallback."""
+    src = [os.path.join(REPO, 'oracle', f) for f in ('flame_ref.c', 'filters_ref.c')]
+    out = os.path.join(tempfile.gettempdir(), 'libflame_ref_native_%d.so' % os.getuid())
+    cmd = ['gcc', '-O3', '-march=native', '-fPIC', '-std=gnu11', '-ffp-contract=off', '-fno-fast-math', '-pthread',
+           '-shared', '-o', out] + src + ['-lm', '-lpthread']
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+        ctypes.CDLL(out)
+        return out, '-O3 -march=native'
+    except Exception:
+        return None, '-O2 -march=x86-64-v3 (prebuilt; native build failed)'
+
+
 def cpu_baseline(gnm, prof, seconds):
     """flam3-style CPU chaos game (oracle/flame_ref.c ref_flam3_render) on a bounded sample."""
     sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from oracle import oracle as OM
+    path, flags = native_oracle()
+    if path:
+        OM.LIB_PATH = path
     from common import O, prepare
     F = prepare(gnm, prof)
     cores = usable_cores()
-    # grow the sample until one run takes at least ~80 % of the budget (thread start-up makes
-    # short probes underestimate the rate), capped at 2^33 samples
-    n = (1 << 21) * cores
-    while True:
-        _, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, cores)
-        if secs >= 0.8 * seconds or n >= 2 ** 33:
-            break
-        n = int(min(2 ** 33, max(2 * n, n * seconds / max(secs, 1e-3))))
-    return {'value': round(n / secs / 1e6, 3), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
+
+    def timed(nthreads, budget):
+        # grow the sample until one run takes most of the budget (thread start-up makes short
+        # probes underestimate the rate), capped at 2^33 samples
+        n = (1 << 21) * nthreads
+        while True:
+            _, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, nthreads)
+            if secs >= 0.7 * budget or n >= 2 ** 33:
+                return n, secs
+            n = int(min(2 ** 33, max(2 * n, n * budget / max(secs, 1e-3))))
+
+    n1, s1 = timed(1, 0.25 * seconds)
+    nc, sc = timed(cores, 0.75 * seconds)
+    return {'value': round(nc / sc / 1e6, 3), 'unit': 'Msamples/s', 'cores': cores, 'kind': 'port',
+            'single_thread': {'value': round(n1 / s1 / 1e6, 3), 'unit': 'Msamples/s', 'cores': 1,
+                              'sample': '%d samples, %.1f s' % (n1, s1)},
+            'build': 'gcc ' + flags,
             'sample': '%d samples of the cfg2 flame (1920x1080 histogram, per-thread private float4 '
-                      'accumulators merged at the end), %.1f s wall' % (n, secs)}
+                      'accumulators merged at the end), %.1f s wall' % (nc, sc)}
+
+
+def copy_bandwidth(torch, device):
+    """float4 device copy of 1 GiB: read + write bytes per second (the practical HBM ceiling of this box)."""
+    n = 1 << 26
+    a = torch.ones((n, 4), dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2 * n * 16 / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -73,21 +132,31 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='cfg2')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=16.0, help='CPU baseline budget (0 = skip)')
     ap.add_argument('--preheat-seconds', type=float, default=3.0,
                     help='untimed frames rendered before the W warm-up steps so that the GPU has left its idle '
-                         'power state (a fresh box needs seconds of load before sclk ramps up; the iterate kernel '
-                         'is latency/ALU-bound and runs ~1.6x slower until then)')
+                         'power state (a fresh box needs seconds of load before sclk ramps up)')
+    ap.add_argument('--depth', type=int, default=2,
+                    help='frames queued ahead of the one being waited for (the reference keeps 1, main.py:64-76; '
+                         'a frame takes ~2 ms here, about what the host needs to queue the next one)')
     ap.add_argument('--shard', default='frames', choices=['frames', 'samples'],
                     help="multi-GPU split: whole frames per rank (default, weak scaling, the reference's "
                          "distribute.py model) or the samples of each single frame with one RCCL "
                          "all-reduce of the accumulators (strong scaling; for frames like cfg5)")
     ap.add_argument('--accum', default=os.environ.get('FLAME_ACCUM', 'binned'), choices=['binned', 'atomic'])
+    ap.add_argument('--gather-block', type=int, default=4, help='frames per gather collective')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+
+    from cuburn_amd import configs
+    gnm, prof = configs.CONFIGS[args.config]()
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:          # before anything touches the GPU
+        cpu = cpu_baseline(gnm, prof, args.cpu_seconds)
+
     import torch
     dist = None
     if world > 1:
@@ -106,8 +175,7 @@ def main():
     coll_dev = 'cuda' if world == 1 or dist.get_backend() == 'nccl' else 'cpu'
     torch.cuda.set_device(local)
 
-    from cuburn_amd import configs, profile, render, _lib, distributed as D
-    gnm, prof = configs.CONFIGS[args.config]()
+    from cuburn_amd import profile, render, _lib, distributed as D
     gprof = profile.wrap(prof, gnm)
     nslots = int(os.environ['FLAME_NSLOTS']) if 'FLAME_NSLOTS' in os.environ else None     # None: chosen by image size
     mgr = render.RenderManager(device=local, nslots=nslots, host_seed=42 + rank)
@@ -116,32 +184,23 @@ def main():
         mgr.fuse = int(os.environ['FLAME_FUSE'])
     rdr = render.Renderer(gnm, gprof)
     w, h = gprof.width, gprof.height
-    frame = torch.empty((h, w, 4), dtype=torch.uint8, device=coll_dev)
-    gathered = [torch.empty_like(frame) for _ in range(world)] if (world > 1 and rank == 0) else None
     tc = 0.5
+    dev = torch.device('cuda', local) if coll_dev == 'cuda' else torch.device('cpu')
+    gather = D.FrameGather((h, w, 4), torch.uint8, dev, block=args.gather_block) if (world > 1 and args.shard == 'frames') else None
 
-    def finish(evt, h_out):
-        """Wait for a queued frame; multi-GPU: hand it to the RCCL gather (frames are the only exchange)."""
-        evt.synchronize()
-        if world > 1:
-            frame.copy_(torch.from_numpy(h_out), non_blocking=False)
-            dist.gather(frame, gathered, dst=0)
+    def queue(slot):
+        if args.shard == 'samples':
+            return D.queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=local)
+        if slot is not None and slot.is_cuda:          # the frame goes straight into the tensor RCCL gathers
+            return mgr.queue_frame(rdr, gnm, gprof, tc, dev_out=slot.data_ptr(), host=False)
+        return mgr.queue_frame(rdr, gnm, gprof, tc)
+
+    def stage(slot, h_out):                             # CPU collectives (gloo dry run): host frame -> slot
+        if slot is not None and not slot.is_cuda:
+            slot.copy_(torch.from_numpy(np.asarray(h_out)))
 
     def run(nframes):
-        """The double-buffered frame loop of the reference (main.py:64-76): queue frame k+1, then wait for frame k."""
-        if args.shard == 'samples':
-            for _ in range(nframes):
-                evt, _h = D.queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=local)
-                evt.synchronize()
-            return
-        pending = None
-        for _ in range(nframes):
-            nxt = mgr.queue_frame(rdr, gnm, gprof, tc)
-            if pending is not None:
-                finish(*pending)
-            pending = nxt
-        if pending is not None:
-            finish(*pending)
+        D.run_frame_loop(queue, nframes, depth=1 if args.shard == 'samples' else args.depth, gather=gather, stage=stage)
 
     def fence():
         if world > 1:
@@ -152,13 +211,7 @@ def main():
     # numbers of them and deadlock): plain local frames, no gather / all-reduce.
     t_heat = time.perf_counter()
     while time.perf_counter() - t_heat < args.preheat_seconds:
-        pend = None
-        for _ in range(4):
-            nxt = mgr.queue_frame(rdr, gnm, gprof, tc)
-            if pend is not None:
-                pend[0].synchronize()
-            pend = nxt
-        pend[0].synchronize()
+        D.run_frame_loop(lambda slot: mgr.queue_frame(rdr, gnm, gprof, tc), 4, depth=args.depth)
     fence()
     run(args.warmup)
     fence()
@@ -166,66 +219,76 @@ def main():
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    samples_per_frame = mgr.last_nsamples
 
-    # Kernel-level numbers (roofline of k_iter, DE-filter GB/s) are taken un-overlapped: a second
-    # context with ONE stream lane renders a few frames, its HIP-event kernel times are what
-    # rocprofv3 --kernel-trace reports for the same command line with FLAME_LANES=1
-    # (profiles/).  `value` above comes from the real two-lane pipeline.
+    # the same loop at the reference's fuse (256 write-disabled rounds at the start of every frame)
+    fuse_main = mgr.fuse
+    mgr.fuse = 256
+    run(min(args.warmup, 2))
+    fence()
+    t1 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed_ref = time.perf_counter() - t1
+    mgr.fuse = fuse_main
+
+    # Kernel-level numbers are taken un-overlapped: a second context with ONE stream lane renders
+    # a few frames back to back (nothing overlaps, but the GPU never idles between kernels, as in
+    # the rocprofv3 runs of profiles/, which use FLAME_LANES=1 too).
     ksteps = max(4, min(args.steps, 16))
     os.environ['FLAME_LANES'] = '1'
     kmgr = render.RenderManager(device=local, nslots=nslots, host_seed=1042 + rank)
     del os.environ['FLAME_LANES']
     kmgr.accum_mode, kmgr.fuse = mgr.accum_mode, mgr.fuse
     krdr = render.Renderer(gnm, gprof)
-    # frames are queued back to back (one lane: nothing overlaps, but the GPU never idles between
-    # kernels, as in the rocprofv3 runs): a frame-by-frame loop lets the clocks sag between frames
-    prev = None
-    for k in range(ksteps + 2):
-        if k == 2:
-            if prev is not None:
-                prev.synchronize()
-                prev = None
-            kmgr.timings_reset()
-        e, _ = kmgr.queue_frame(krdr, gnm, gprof, tc)
-        if prev is not None:
-            prev.synchronize()
-        prev = e
-    prev.synchronize()
-    acc = kmgr.timings()
-    acc['samples'] = kmgr.last_nsamples * ksteps
-    acc['steps'] = ksteps
+
+    def kernel_times(fuse):
+        kmgr.fuse = fuse
+        D.run_frame_loop(lambda slot: kmgr.queue_frame(krdr, gnm, gprof, tc), 2, depth=1)
+        kmgr.timings_reset()
+        D.run_frame_loop(lambda slot: kmgr.queue_frame(krdr, gnm, gprof, tc), ksteps, depth=1)
+        t = kmgr.timings()
+        t['samples'] = kmgr.last_nsamples * ksteps
+        return t
+    acc = kernel_times(fuse_main)
+    acc_ref = kernel_times(256)
     fence()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        tt = torch.tensor([elapsed, elapsed_ref], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    job_samples_per_step = mgr.last_nsamples * world            # frames: every rank runs the same workload
+        elapsed, elapsed_ref = float(tt[0].item()), float(tt[1].item())
+    job_samples_per_step = samples_per_frame * world            # frames: every rank runs the same workload
     if world > 1 and args.shard == 'samples':
-        ns = torch.tensor([mgr.last_nsamples], dtype=torch.float64, device=coll_dev)
+        ns = torch.tensor([samples_per_frame], dtype=torch.float64, device=dev)
         dist.all_reduce(ns)
         job_samples_per_step = int(ns.item())
 
     if rank == 0:
         dim = render.Framebuffers.calc_dim(w, h)
         nbins = dim.ah * dim.astride
-        samples_total = job_samples_per_step * args.steps
-        iter_s = acc['iter_ms'] * 1e-3
-        achieved = 16.0 * acc['samples'] / iter_s / 1e9 if iter_s > 0 else 0.0
-        pipe_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
-        pipe = 16.0 * acc['samples'] / pipe_s / 1e9 if pipe_s > 0 else 0.0
-        traffic = None
+        copy_gbs = copy_bandwidth(torch, torch.device('cuda', local)) if world == 1 else None
+        chain_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
+        chain = 16.0 * acc['samples'] / chain_s / 1e9 if chain_s > 0 else 0.0
+        chain_ref_s = (acc_ref['iter_ms'] + acc_ref['flush_ms']) * 1e-3
+        traffic, iter_bytes = None, None
         try:        # measured offline with tools/pmc_traffic.sh on this workload (KB units, reads x2)
-            pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')))
-            key = [k for k in pmc if 'k_iter' in k and ((', 1>' in k) == (args.accum == 'binned'))]
-            if key and args.config == 'cfg2':
-                c = pmc[key[0]]
-                traffic = int((2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024)
+            pmc = json.load(open(os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')))
+            def kb(sub):
+                ks = [k for k in pmc if sub in k]
+                c = pmc[ks[0]]
+                return (2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024
+            if args.config == 'cfg2' and args.accum == 'binned':
+                iter_bytes = int(kb('k_iter'))
+                traffic = int(iter_bytes + kb('k_accum_tiles') + kb('k_flush'))
         except Exception:
-            traffic = None
-        de_bytes = 512.0 * nbins * acc['steps']            # 64 B/px/direction x 8
+            traffic, iter_bytes = None, None
+        launches = max(acc['launches'], 1)
+        iter_launch_s = acc['iter_ms'] * 1e-3 / launches
+        de_s = (acc['de_ms'] + acc['de_finish_ms']) * 1e-3 / ksteps
+        de_gbs = 512.0 * nbins / de_s / 1e9 if de_s > 0 else 0.0            # 64 B/px/direction x 8
         out = {
             'metric': 'Msamples/s into 1920x1080 histogram + DE-filter GB/s vs HBM roofline',
-            'value': round(samples_total / elapsed / 1e6, 2),
+            'value': round(job_samples_per_step * args.steps / elapsed / 1e6, 2),
             'unit': 'Msamples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
@@ -233,23 +296,38 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
-                       'samples_per_frame': mgr.last_nsamples if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
-                       'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': mgr.fuse, 'nslots': mgr.fb.nslots, 'frames_per_gpu': args.steps,
-                       'parallelism': ('frame-sharded x%d, RCCL gather' if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators') % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_iter', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                         'pipeline': {'kernels': 'k_iter+k_accum_tiles+k_flush', 'achieved': round(pipe, 2), 'frac': round(pipe / HBM_PEAK_GBS, 5)},
-                         'avg_launch_ms': round(acc['iter_ms'] / max(acc['launches'], 1), 4),
-                         'iter_msamples_per_s': round(acc['samples'] / iter_s / 1e6, 1) if iter_s > 0 else 0.0},
-            'de_filter': {'gbps': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9, 2) if acc['filter_ms'] > 0 else 0.0,
-                          'frac_of_peak': round(de_bytes / (acc['filter_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if acc['filter_ms'] > 0 else 0.0,
-                          'note': 'algorithmic 512 B/px over the whole filter chain time (yuv+bilateral+logscale+colorclip)',
-                          'filter_ms_per_frame': round(acc['filter_ms'] / acc['steps'], 4)},
-            'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / acc['steps'], 4), 'accum_flush': round(acc['flush_ms'] / acc['steps'], 4),
-                                    'filters': round(acc['filter_ms'] / acc['steps'], 4), 'note': 'un-overlapped (single stream lane)'},
+                       'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
+                       'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
+                       'frames_queued_ahead': args.depth, 'frames_per_gpu': args.steps,
+                       'per_genome_kernel': os.environ.get('FLAME_RTC', '1') != '0',
+                       'fuse_reference': {'fuse': 256, 'value': round(job_samples_per_step * args.steps / elapsed_ref / 1e6, 2),
+                                          'ms_per_step': round(elapsed_ref / args.steps * 1e3, 3),
+                                          'iter_chain_ms_per_frame': round(chain_ref_s / ksteps * 1e3, 4),
+                                          'note': 'the reference spends one 256-iteration round block per frame on un-plotted iterations '
+                                                  '(render.py:215); value counts write-enabled samples only'},
+                       'parallelism': ('frame-sharded x%d, RCCL gather of device frames, %d frames per collective' % (world, args.gather_block)
+                                       if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators' % world)},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_iter + k_accum_tiles + k_flush (iterate chain: the 8-byte packed-cell RMW per sample)',
+                         'achieved': round(chain, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(chain / HBM_PEAK_GBS, 5),
+                         'traffic': traffic,
+                         'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
+                         'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
+                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'VALU / SALU issue (not bandwidth)',
+                                    'measured_bytes_per_launch': iter_bytes,
+                                    'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
+                                    'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
+                         'k_accum_tiles_ms_per_frame': round(acc['accum_ms'] / ksteps, 4),
+                         'k_flush_ms_per_frame': round(acc['flush_only_ms'] / ksteps, 4)},
+            'de_filter': {'kernels': 'k_de_normalise + 8 x k_de_dir + k_de_finish_tone', 'ms_per_frame': round(de_s * 1e3, 4),
+                          'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
+                          'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
+                          'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
+                          'bound': 'VALU issue (SQ counters in profiles/): 512 B/px is the algorithmic byte count of the reference pass structure'},
+            'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),
+                                    'filters': round(acc['filter_ms'] / ksteps, 4), 'note': 'un-overlapped (single stream lane)'},
         }
-        if world == 1 and args.cpu_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(gnm, prof, args.cpu_seconds)
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -46,6 +46,7 @@ _SIGS = {
     'fl_timings_reset': (C.c_int, [C.c_void_p]),
     'fl_timings': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                              C.POINTER(C.c_uint32)]),
+    'fl_timings_detail': (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 6)]),
     'fl_read_buffer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     'fl_write_buffer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     'fl_buffer_ptr': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -56,6 +57,7 @@ _SIGS = {
     'fl_debug_clear_hot': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     'fl_debug_shuffle': (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     'fl_debug_counters': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'fl_rtc_compile_check': (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     'fl_debug_apply_xf': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = sorted(_SIGS)

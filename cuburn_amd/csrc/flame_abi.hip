@@ -75,11 +75,12 @@ struct fl_ctx {
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
     uint32_t frame_lane[kFrames] = {};
     uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
-    std::vector<EvPair> pool, iter_ev, flush_ev, filt_ev, de_ev;
+    std::vector<EvPair> pool, iter_ev, accum_ev, flush_ev, filt_ev, de_ev, definish_ev;
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
     bool env_bin_wide = false, env_de_reference = false, env_de_gather = false, env_de_aos = false, env_de_split = false;
+    bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
 };
 #define L(c) ((c)->lanes[(c)->cur])
 #define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
@@ -87,6 +88,9 @@ struct fl_ctx {
 
 struct fl_genome {
     std::vector<int32_t> prog;
+    IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
+    hipFunction_t rtc_fn[2][2][4] = {};     // [nw == 8][count][acc] once compiled
+    bool rtc_failed = false;                // compile / load failed once: stay on the interpreter kernel
     uint32_t nops = 0, nrows = 0, pstride = 0;
     int32_t *d_prog = nullptr, *d_ops = nullptr;
     float *d_times = nullptr, *d_knots = nullptr, *d_ptimes = nullptr;
@@ -218,6 +222,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     c->env_de_gather = env_on("FLAME_DE_GATHER");
     c->env_de_aos = env_on("FLAME_DE_LDS_AOS");
+    if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
     c->env_de_split = env_on("FLAME_DE_SPLIT") || c->env_de_aos;      // previous form: blur kernel + bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
@@ -363,8 +368,27 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
         }
     }
     for (int i = 0; i < nrec; ++i) REQUIRE(nvar_seen[i] >= 0, "xform record without a variation count");
+    // structure tables for the specialised kernel: counts / post flags / variation numbers per record
+    IterSpec spec;
+    spec.nxf = prog[1]; spec.has_final = prog[2]; spec.pstride = prog[3]; spec.cdf_off = prog[4];
+    spec.xf_off = xo; spec.xf_stride = xs; spec.var_stride = vs;
+    spec.nvar.assign(nrec, 0); spec.post.assign(nrec, 0); spec.vids.assign(nrec, std::vector<int>());
+    for (int i = 0; i < nrec; ++i) spec.vids[i].assign(nvar_seen[i], -1);
+    for (uint32_t i = 0; i < nops; ++i) {
+        const int32_t *o = ops + 4 * i;
+        if (o[0] != FL_OP_CONST) continue;
+        const int rel = o[1] - xo, rec = rel / xs, w = rel % xs;
+        if (w == 14) { spec.nvar[rec] = o[2] & 0xff; spec.post[rec] = (o[2] >> 8) & 1; }
+        else {
+            const int j = (w - FL_XF_HDR) / vs;
+            if (j < (int)spec.vids[rec].size()) spec.vids[rec][j] = o[2];
+        }
+    }
+    for (int i = 0; i < nrec; ++i)
+        for (int v : spec.vids[i]) REQUIRE(v >= 0, "variation record without a variation number");
     HIPCHK(hipSetDevice(c->device));
     fl_genome *g = new fl_genome;
+    g->spec = spec;
     g->prog.assign(prog, prog + nprog);
     g->nops = nops; g->nrows = nrows; g->pstride = ps;
     g->stage_bytes = 2 * 4 * (size_t)nrows * FL_KNOTS + 16 * 256 * (FL_KNOTS - 1) + 4 * FL_KNOTS;
@@ -523,14 +547,36 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         if (rc) return rc;
     }
     EvPair *e = ev_pair(c, c->iter_ev);
-    launch_iter(L(c).stream, c->nw, count, acc == FL_ACCUM_BINNED && wide ? 3 : acc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
+    const int kacc = acc == FL_ACCUM_BINNED && wide ? 3 : acc;
+    // the kernel specialised for this genome's structure (compiled on first use, rtc.hip); the
+    // interpreter kernel if hipRTC is unavailable, switched off, or the compile failed
+    hipFunction_t fn = nullptr;
+    if (c->use_rtc && !g->rtc_failed && kacc != 2) {
+        hipFunction_t &slot = g->rtc_fn[c->nw == 8][count ? 1 : 0][kacc];
+        if (!slot) {
+            std::string err;
+            if (rtc_iter_kernel(c->device, g->spec, c->nw, count, kacc, &slot, &err)) {
+                g->rtc_failed = true;
+                slot = nullptr;
+                fprintf(stderr, "libflame_hip: per-genome kernel not available (%s); using the interpreter kernel\n", err.c_str());
+            }
+        }
+        fn = slot;
+    }
+    if (fn)
+        launch_iter_fn(L(c).stream, fn, c->nw, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
+                       L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
+                       tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir,
+                       e ? e->a : nullptr, e ? e->b : nullptr);
+    else
+    launch_iter(L(c).stream, c->nw, count, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                 tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir,
                 e ? e->a : nullptr, e ? e->b : nullptr);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
-        EvPair *e2 = ev_begin(c, c->flush_ev);
+        EvPair *e2 = ev_begin(c, c->accum_ev);
         // workgroups per tile: enough of them to fill the chip several times over (~8192 in all),
         // no more — every workgroup zeroes and drains a whole LDS tile whatever its share of records
         uint32_t parts = c->bin_parts ? c->bin_parts : 8192u / nbins;
@@ -628,6 +674,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     if (rc) return rc;
     hipStream_t st = L(c).stream;
     float k7[7];
+    bool ran_finish = false;
     EvPair *e = ev_begin(c, c->filt_ev);
     switch (id) {
     case FL_FILT_YUV:
@@ -702,6 +749,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         if (L(c).pend_finish && !L(c).pend_yuv) {
             launch_de_finish_tone(st, d, L(c).d_front, L(c).pend_N, L(c).pend_log, L(c).pend_k1, L(c).pend_k2, true, p);
             L(c).pend_finish = L(c).pend_log = false;
+            ran_finish = true;
             break;
         }
         flush_pending(c);
@@ -742,6 +790,8 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         return fail(FL_E_UNSUPPORTED, "unknown filter id", __FILE__, __LINE__);
     }
     ev_end(c, e);
+    if (e && id == FL_FILT_BILATERAL) c->de_ev.push_back(*e);                 // normalise + 8 directions
+    if (e && ran_finish) c->definish_ev.push_back(*e);                        // un-normalise (+ logscale + colorclip riding along)
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -806,7 +856,16 @@ int fl_timings_reset(fl_ctx *c)
 {
     REQUIRE(c, "null ctx");
     sync_all(c);
-    c->iter_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->pool_used = 0;
+    c->iter_ev.clear(); c->accum_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->de_ev.clear(); c->definish_ev.clear(); c->pool_used = 0;
+    return FL_OK;
+}
+
+int fl_timings_detail(fl_ctx *c, float ms[6])
+{
+    REQUIRE(c && ms, "null argument");
+    sync_all(c);
+    ms[0] = sum_ms(c->iter_ev); ms[1] = sum_ms(c->accum_ev); ms[2] = sum_ms(c->flush_ev);
+    ms[3] = sum_ms(c->filt_ev); ms[4] = sum_ms(c->de_ev); ms[5] = sum_ms(c->definish_ev);
     return FL_OK;
 }
 
@@ -815,7 +874,7 @@ int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uin
     REQUIRE(c, "null ctx");
     sync_all(c);
     if (iter_ms) *iter_ms = sum_ms(c->iter_ev);
-    if (flush_ms) *flush_ms = sum_ms(c->flush_ev);
+    if (flush_ms) *flush_ms = sum_ms(c->accum_ev) + sum_ms(c->flush_ev);
     if (filter_ms) *filter_ms = sum_ms(c->filt_ev);
     if (nlaunch) *nlaunch = (uint32_t)c->iter_ev.size();
     return FL_OK;
@@ -956,6 +1015,33 @@ int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n,
     HIPCHK(hipMemcpy(xyzw, dp.p, 16 * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rng, dr.p, sizeof(fl_mwc) * (size_t)n, hipMemcpyDeviceToHost));
     return FL_OK;
+}
+
+int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
+                         char *log, size_t log_bytes)
+{
+    REQUIRE(prog && ops && nprog >= FL_PROG_HDR && (nw == 4 || nw == 8) && acc >= 0 && acc <= 3, "bad argument");
+    int rc = check_prog(prog, nprog);
+    if (rc) return rc;
+    const int xo = prog[5], xs = prog[6], vs = prog[7], nrec = prog[1] + prog[2];
+    IterSpec spec;
+    spec.nxf = prog[1]; spec.has_final = prog[2]; spec.pstride = prog[3]; spec.cdf_off = prog[4];
+    spec.xf_off = xo; spec.xf_stride = xs; spec.var_stride = vs;
+    spec.nvar.assign(nrec, 0); spec.post.assign(nrec, 0); spec.vids.assign(nrec, std::vector<int>(16, 0));
+    for (uint32_t i = 0; i < nops; ++i) {
+        const int32_t *o = ops + 4 * i;
+        if (o[0] != FL_OP_CONST) continue;
+        const int rel = o[1] - xo, rec = rel / xs, w = rel % xs;
+        REQUIRE(rel >= 0 && rec < nrec, "structure word outside the xform records");
+        if (w == 14) { spec.nvar[rec] = o[2] & 0xff; spec.post[rec] = (o[2] >> 8) & 1; }
+        else { const int j = (w - FL_XF_HDR) / vs; if (j >= (int)spec.vids[rec].size()) spec.vids[rec].resize(j + 1, 0); spec.vids[rec][j] = o[2]; }
+    }
+    std::vector<char> code;
+    std::string err;
+    rc = rtc_compile(spec, nw, count != 0, acc, &code, &err);
+    if (log && log_bytes) { snprintf(log, log_bytes, "%s", rc ? err.c_str() : "ok"); }
+    if (rc) return fail(rtc_available() ? FL_E_HIP : FL_E_UNSUPPORTED, "per-genome kernel did not compile", __FILE__, __LINE__);
+    return (int)(code.size() > 0 ? FL_OK : FL_E_HIP);
 }
 
 int fl_debug_counters(fl_ctx *c, uint64_t out4[4])

@@ -1,9 +1,21 @@
 // flame_device.h — device-side helpers shared by the gfx950 kernels: MWC RNG, packed
 // accumulator cell, fast math wrappers.  (Product code; independent of oracle/.)
 #pragma once
+#ifdef __HIPCC_RTC__
+// hipRTC: the HIP device declarations are built in; no system headers
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long size_t;
+#include "flame_hip.h"
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/flame_hip.h"
+#endif
 
 typedef unsigned long long u64;
 

@@ -15,9 +15,18 @@
 //     round), three-phase destination pattern so no pair shares a wave 3 rounds running;
 //   * samples are accumulated as 64-bit packed cells with global atomics whose returned
 //     value is examined one round later (latency hidden) to drain nearly-full cells.
+//
+// This file is compiled twice: ahead of time into libflame_hip.so (one kernel that INTERPRETS the
+// genome's structure), and at run time by hipRTC (FL_RTC, rtc.hip) with the structure of ONE genome
+// as compile-time tables — the native counterpart of the reference compiling a CUDA module per
+// genome (cuburn/render.py:232-236, cuburn/code/iter.py:559-575): the variation dispatch, the
+// variation loop, the post-affine test and the final-xform test disappear from the round loop.
+// Both builds execute the same arithmetic in the same order (bit-identical results).
 #include "variations.h"
+#ifndef FL_RTC
 #include "kernels.h"
 #include <hip/hip_ext.h>
+#endif
 
 template <int NW>
 __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_t phase) {
@@ -64,6 +73,56 @@ __device__ __forceinline__ void apply_xf(const XfHead &h, const float *__restric
     c = fmaf(c, 1.0f - csp, h.f[12] * csp);
     x = ox; y = oy;
 }
+
+#ifdef FL_RTC
+// Structure tables of the genome this translation unit is compiled for (generated header
+// "flame_spec.h": rtc.hip): FL_SPEC_NXF selectable xforms + FL_SPEC_FINAL, per record its number of
+// variations, whether it has a post affine, and its variation numbers in order.
+#include "flame_spec.h"
+
+template <int I, int J>
+__device__ __forceinline__ void spec_variations(const float *__restrict__ xf, float w0, float &tx, float &ty,
+                                                float &ox, float &oy, mwc_t &r)
+{
+    if constexpr (J < kSpecNvar[I]) {
+        const float *__restrict__ v = xf + FL_XF_HDR + J * FL_SPEC_VAR_STRIDE;
+        apply_variation_body(kSpecVid[I][J], J == 0 ? w0 : v[1], v + 2, xf, tx, ty, ox, oy, r);
+        spec_variations<I, J + 1>(xf, w0, tx, ty, ox, oy, r);
+    }
+}
+
+// apply_xf with the structure of record I known at compile time (same arithmetic, same order)
+template <int I>
+__device__ __forceinline__ void spec_apply_xf(const XfHead &h, const float *__restrict__ xf,
+                                              float &x, float &y, float &c, mwc_t &r)
+{
+    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, h.f[2]));
+    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, h.f[5]));
+    float ox = 0.0f, oy = 0.0f;
+    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
+    if constexpr (kSpecPost[I] != 0) {
+        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, h.f[8]));
+        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, h.f[11]));
+        ox = qx; oy = qy;
+    }
+    const float csp = h.f[13];
+    c = fmaf(c, 1.0f - csp, h.f[12] * csp);
+    x = ox; y = oy;
+}
+
+// wave-uniform dispatch over the selectable xforms [LO, HI): a binary tree of scalar compares
+template <int LO, int HI>
+__device__ __forceinline__ void spec_dispatch(int k, const XfHead &h, const float *__restrict__ xf,
+                                              float &x, float &y, float &c, mwc_t &r)
+{
+    if constexpr (HI - LO == 1) spec_apply_xf<LO>(h, xf, x, y, c, r);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        if (k < MID) spec_dispatch<LO, MID>(k, h, xf, x, y, c, r);
+        else spec_dispatch<MID, HI>(k, h, xf, x, y, c, r);
+    }
+}
+#endif
 
 // cuburn/code/iter.py:366-406: if the cell had reached 512 hits, swap it with zero and add its
 // unpacked contents (weighted by the hot-pixel multiplier) to the float accumulator.
@@ -121,21 +180,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t) {
 // ACC: 0 = packed global atomics, 1 = binned (sample log, 128x64 tiles, tile number inside the staged
 // record), 2 = none (measurement of the walk), 3 = binned for images with more than 2047 tiles
 // (256x64 tiles, tile numbers staged in a separate 16-bit array)
-template <int NW, bool COUNT, int ACC>
-__global__ void __launch_bounds__(NW * 64)
-k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
-       const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points,
-       const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4,
-       u64 *__restrict__ counters, uint32_t astride, uint32_t aheight,
-       uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg,
-       uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir)
+template <int NW, bool COUNT, int ACC, bool SPEC>
+__device__ __forceinline__ void
+iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__restrict__ params,
+          const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points,
+          const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4,
+          u64 *__restrict__ counters, uint32_t astride, uint32_t aheight,
+          uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg,
+          uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir)
 {
     constexpr int NT = NW * 64;
     constexpr bool BINNED = ACC == 1 || ACC == 3, WIDE = ACC == 3;
     constexpr uint32_t TWL = WIDE ? FL_TILE_W_WIDE_LOG2 : 7u;          // log2 of the tile width
     constexpr uint32_t PAY_BITS = TWL + FL_TILE_H_LOG2 + 8u;          // row | column | palette column
     // all LDS is carved from the dynamic region (16-byte aligned pieces)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float (*swp)[3][NT] = reinterpret_cast<float (*)[3][NT]>(smem);                    // [2][3][NT]
     u64 *palrow = reinterpret_cast<u64 *>(smem + 2 * 3 * NT * 4);                      // [256]   (not binned)
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (binned)
@@ -146,8 +204,14 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const uint32_t slot = blockIdx.x, ts = slot, prow = slot * FL_PAL_H / gridDim.x;
+#ifdef FL_RTC
+    const int nxf = SPEC ? FL_SPEC_NXF : prog[1], has_final = SPEC ? FL_SPEC_FINAL : prog[2], pstride = SPEC ? FL_SPEC_PSTRIDE : prog[3];
+    const int cdf_off = SPEC ? FL_SPEC_CDF_OFF : prog[4], xf_off = SPEC ? FL_SPEC_XF_OFF : prog[5];
+    const int xf_stride = SPEC ? FL_SPEC_XF_STRIDE : prog[6], var_stride = SPEC ? FL_SPEC_VAR_STRIDE : prog[7];
+#else
     const int nxf = prog[1], has_final = prog[2], pstride = prog[3], cdf_off = prog[4];
     const int xf_off = prog[5], xf_stride = prog[6], var_stride = prog[7];
+#endif
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
     if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[prow * FL_PAL_W + i];
@@ -187,19 +251,26 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         return min((int)__builtin_ctzll(le), nxf - 1);
     };
     uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
-    const float *__restrict__ xf_next = P + xf_off + choose(sel_next) * xf_stride;
+    int k_next = choose(sel_next);
+    const float *__restrict__ xf_next = P + xf_off + k_next * xf_stride;
     XfHead hnext = load_head(xf_next);
 
     for (uint32_t rd = 0; rd < nrounds; ++rd) {
         if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
 
-        const uint32_t sel = sel_next;
+        const int k_cur = k_next;
         const float *__restrict__ xf_cur = xf_next;
         const XfHead hcur = hnext;
         sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
-        xf_next = P + xf_off + choose(sel_next) * xf_stride;
+        k_next = choose(sel_next);
+        xf_next = P + xf_off + k_next * xf_stride;
         hnext = load_head(xf_next);                                         // arrives during this round
+#ifdef FL_RTC
+        if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hcur, xf_cur, x, y, color, rctx);
+        else
+#endif
         apply_xf(hcur, xf_cur, var_stride, x, y, color, rctx);
+        (void)k_cur;
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
@@ -212,6 +283,11 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
         if (rd < fuse) continue;                                            // iter.py:298-300
 
         float fx = x, fy = y, fc = color;
+#ifdef FL_RTC
+        if constexpr (SPEC) {
+            if constexpr (FL_SPEC_FINAL != 0) { const XfHead hfin = load_head(xf_final); spec_apply_xf<FL_SPEC_NXF>(hfin, xf_final, fx, fy, fc, rctx); }
+        } else
+#endif
         if (has_final) { const XfHead hfin = load_head(xf_final); apply_xf(hfin, xf_final, var_stride, fx, fy, fc, rctx); }   // iter.py:302-307
         const float cx = fmaf(cam0, fx, fmaf(cam1, fy, cam2));              // iter.py:306-309
         const float cy = fmaf(cam3, fx, fmaf(cam4, fy, cam5));
@@ -325,6 +401,30 @@ k_iter(const int32_t *__restrict__ prog, const float *__restrict__ params,
     }
 }
 
+#define FL_ITER_ARGS const int32_t *__restrict__ prog, const float *__restrict__ params, \
+       const u64 *__restrict__ palette, fl_mwc *__restrict__ rng, float4 *__restrict__ points, \
+       const uint32_t *__restrict__ hot, u64 *__restrict__ atom, float *__restrict__ out4, \
+       u64 *__restrict__ counters, uint32_t astride, uint32_t aheight, \
+       uint32_t round0, uint32_t nrounds, uint32_t fuse, BinGeom bg, \
+       uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir
+#define FL_ITER_PASS prog, params, palette, rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg, bin_log, bin_dir
+
+#ifdef FL_RTC
+// the kernel of ONE genome structure, walker geometry and accumulate mode (rtc.hip compiles it on
+// first use and caches the code object)
+extern "C" __global__ void __launch_bounds__(FL_SPEC_NW * 64) k_iter_spec(FL_ITER_ARGS)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    iter_body<FL_SPEC_NW, FL_SPEC_COUNT != 0, FL_SPEC_ACC, true>(smem, FL_ITER_PASS);
+}
+#else
+template <int NW, bool COUNT, int ACC>
+__global__ void __launch_bounds__(NW * 64) k_iter(FL_ITER_ARGS)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    iter_body<NW, COUNT, ACC, false>(smem, FL_ITER_PASS);
+}
+
 // Xform tap: apply xform `xfi` of temporal sample `ts` once to n independent points (one per
 // thread, own RNG state).  For the per-variation parity tests.
 __global__ void __launch_bounds__(256)
@@ -429,6 +529,21 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
 #undef LAUNCH
 }
 
+void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t nslots,
+                    const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
+                    float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
+                    uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
+                    uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
+                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total};
+    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins);
+    void *args[] = {&prog, &params, &palette, &rng, &points, &hot, &atom, &out4, &counters, &astride, &aheight,
+                    &round0, &nrounds, &fuse, &bg, &log, &dir};
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipExtModuleLaunchKernel(fn, nslots * (uint32_t)nw * 64, 1, 1, (uint32_t)nw * 64, 1, 1, lds, st, args, nullptr, ev_start, ev_stop, 0);
+}
+
 void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot)
 {
     hipLaunchKernelGGL(k_flush, dim3((nbins + 255) / 256), dim3(256), 0, st, atom, out, hot, nbins, use_hot ? 1 : 0);
@@ -439,3 +554,4 @@ void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round)
     if (nw == 4) hipLaunchKernelGGL(k_shuffle_tap<4>, dim3(1), dim3(256), 0, st, out, round);
     else hipLaunchKernelGGL(k_shuffle_tap<8>, dim3(1), dim3(512), 0, st, out, round);
 }
+#endif  // !FL_RTC

@@ -30,6 +30,25 @@ void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
 void launch_apply_xf_tap(hipStream_t st, const int32_t *prog, const float *params, uint32_t ts, int xfi,
                          uint32_t n, float4 *pts, fl_mwc *rng);
 
+// rtc.hip: structure of a genome as the run-time specialised iterate kernel needs it (include/flame_hip.h (5))
+#include <string>
+#include <vector>
+struct IterSpec {
+    int nxf = 0, has_final = 0, pstride = 0, cdf_off = 0, xf_off = 0, xf_stride = 0, var_stride = 0;
+    std::vector<int> nvar, post;                 // per record (selectable xforms, then the final xform)
+    std::vector<std::vector<int>> vids;          // flam3 variation numbers in application order
+};
+bool rtc_available();
+int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err);
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err);
+// launch_iter through a run-time compiled kernel (same arguments)
+void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t nslots,
+                    const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
+                    float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
+                    uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
+                    uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
+                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 // binned.hip
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
                         u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,

@@ -1,0 +1,146 @@
+// rtc.hip — per-genome specialisation of the iterate kernel with hipRTC.
+//
+// The reference generates and compiles CUDA source for every genome (cuburn/render.py:232-236,
+// cuburn/code/iter.py:559-575, Tempita + nvcc through PyCUDA, up to 20 modules cached,
+// render.py:229-245).  Here one precompiled kernel interprets any genome; on top of it the STRUCTURE
+// of a genome (xform count, variation numbers per xform, post affines, final xform, record strides)
+// can be compiled into the same kernel source at run time: iter.hip is rebuilt by hipRTC with the
+// structure as constexpr tables ("flame_spec.h", generated below), which removes the variation
+// dispatch, the variation loop and the post / final tests from the round loop.  All VALUES (affine
+// coefficients, weights, variation parameters) stay data in the parameter block, so an animation
+// whose structure does not change compiles once.  Code objects are cached per process by
+// (device, structure, walker geometry, accumulate mode).  libhiprtc is loaded with dlopen: without it
+// (or with FLAME_RTC=0) the interpreter kernel runs — same results, bit for bit.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "kernels.h"
+#include "rtc_sources.inc"
+
+namespace {
+
+struct Api {
+    bool ok = false;
+    hiprtcResult (*create)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    hiprtcResult (*compile)(hiprtcProgram, int, const char **) = nullptr;
+    hiprtcResult (*log_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*log)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*code_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*code)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*destroy)(hiprtcProgram *) = nullptr;
+};
+
+Api load_api()
+{
+    Api a;
+    void *h = nullptr;
+    for (const char *name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return a;
+#define SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, sym)); if (!a.field) return a
+    SYM(create, "hiprtcCreateProgram"); SYM(compile, "hiprtcCompileProgram");
+    SYM(log_size, "hiprtcGetProgramLogSize"); SYM(log, "hiprtcGetProgramLog");
+    SYM(code_size, "hiprtcGetCodeSize"); SYM(code, "hiprtcGetCode"); SYM(destroy, "hiprtcDestroyProgram");
+#undef SYM
+    a.ok = true;
+    return a;
+}
+
+const Api &api() { static Api a = load_api(); return a; }
+
+struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; };
+std::mutex g_mu;
+std::map<std::string, Entry> g_cache;           // key: device + generated header
+const size_t kMaxModules = 64;                  // (the reference keeps 20, render.py:229)
+
+std::string spec_header(const IterSpec &s, int nw, bool count, int acc)
+{
+    const int nrec = s.nxf + s.has_final;
+    int maxv = 1;
+    for (int i = 0; i < nrec; ++i) maxv = std::max(maxv, s.nvar[i]);
+    std::string h = "// generated: structure of one genome (rtc.hip)\n";
+    char buf[256];
+#define DEF(name, val) snprintf(buf, sizeof buf, "#define %s %d\n", name, (int)(val)); h += buf
+    DEF("FL_SPEC_NXF", s.nxf); DEF("FL_SPEC_FINAL", s.has_final); DEF("FL_SPEC_PSTRIDE", s.pstride);
+    DEF("FL_SPEC_CDF_OFF", s.cdf_off); DEF("FL_SPEC_XF_OFF", s.xf_off); DEF("FL_SPEC_XF_STRIDE", s.xf_stride);
+    DEF("FL_SPEC_VAR_STRIDE", s.var_stride); DEF("FL_SPEC_NW", nw); DEF("FL_SPEC_COUNT", count ? 1 : 0); DEF("FL_SPEC_ACC", acc);
+#undef DEF
+    h += "constexpr int kSpecNvar[] = {";
+    for (int i = 0; i < nrec; ++i) h += std::to_string(s.nvar[i]) + ",";
+    h += "0};\nconstexpr int kSpecPost[] = {";
+    for (int i = 0; i < nrec; ++i) h += std::to_string(s.post[i]) + ",";
+    snprintf(buf, sizeof buf, "0};\nconstexpr int kSpecVid[][%d] = {", maxv);
+    h += buf;
+    for (int i = 0; i < nrec; ++i) {
+        h += "{";
+        for (int j = 0; j < maxv; ++j) h += std::to_string(j < s.nvar[i] ? s.vids[i][j] : 0) + ",";
+        h += "},";
+    }
+    h += "{0}};\n";
+    return h;
+}
+
+}  // namespace
+
+bool rtc_available() { return api().ok; }
+
+int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err)
+{
+    const Api &a = api();
+    if (!a.ok) { *err = "libhiprtc not found"; return -1; }
+    const std::string header = spec_header(spec, nw, count, acc);
+    hiprtcProgram prog = nullptr;
+    const char *hdr_src[] = {rtc_src_variations, rtc_src_device, rtc_src_abi, header.c_str()};
+    const char *hdr_name[] = {"variations.h", "flame_device.h", "flame_hip.h", "flame_spec.h"};
+    if (a.create(&prog, rtc_src_iter, "iter.hip", 4, hdr_src, hdr_name) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return -1; }
+    // same code generation options as the ahead-of-time build of iter.hip (csrc/Makefile)
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-DFL_RTC=1",
+                          "-mllvm", "-structurizecfg-skip-uniform-regions=true"};
+    const hiprtcResult rc = a.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        a.log_size(prog, &n);
+        std::string log(n, '\0');
+        if (n) a.log(prog, &log[0]);
+        *err = "hiprtc compile failed: " + log.substr(0, 4000);
+        a.destroy(&prog);
+        return -1;
+    }
+    size_t n = 0;
+    a.code_size(prog, &n);
+    code->resize(n);
+    a.code(prog, code->data());
+    a.destroy(&prog);
+    return 0;
+}
+
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err)
+{
+    const std::string key = std::to_string(device) + "|" + spec_header(spec, nw, count, acc);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) { *fn = it->second.fn; return 0; }
+    std::vector<char> code;
+    if (rtc_compile(spec, nw, count, acc, &code, err)) return -1;
+    Entry e;
+    if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); *err = "hipModuleLoadData failed"; return -1; }
+    if (hipModuleGetFunction(&e.fn, e.mod, "k_iter_spec") != hipSuccess) {
+        (void)hipGetLastError(); (void)hipModuleUnload(e.mod); *err = "k_iter_spec not found in the compiled module"; return -1;
+    }
+    if (g_cache.size() >= kMaxModules) {            // simple bound: drop everything (kernels may still be queued: sync first)
+        (void)hipDeviceSynchronize();
+        for (auto &kv : g_cache) (void)hipModuleUnload(kv.second.mod);
+        g_cache.clear();
+    }
+    g_cache[key] = e;
+    *fn = e.fn;
+    return 0;
+}

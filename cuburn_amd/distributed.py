@@ -79,6 +79,105 @@ def gather_animation(local_frames, nframes, dst=0, shape=None, dtype=None, devic
     return result
 
 
+class FrameGather(object):
+    """
+    The final gather of frame-sharded rendering, off the critical path: every rank renders its own
+    frames straight into ``slot()`` (a device tensor when the backend is RCCL: fl_output's
+    ``dev_out``, no host bounce), ``submit()`` marks the oldest outstanding slot complete, and every
+    ``block`` frames ONE asynchronous gather moves the block to rank ``dst`` (xGMI is point-to-point:
+    a few large messages per peer instead of seven small receives per frame on rank 0).  Two
+    blocks alternate, so a block is only waited for when it is about to be re-used, 2 x block frames
+    later.  All ranks must submit the same number of frames.  ``sink(rank, index, frame)`` is
+    called on ``dst`` for every received frame (index = the rank's own frame counter).
+    """
+
+    def __init__(self, shape, dtype, device, block=4, dst=0, sink=None):
+        self.rank, self.world = _world()
+        self.block, self.dst, self.sink = int(block), dst, sink
+        self.blocks = [torch.zeros((self.block,) + tuple(shape), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [[torch.empty_like(b) for _ in range(self.world)] if (self.world > 1 and self.rank == dst) else None
+                     for b in self.blocks]
+        self.work = [None, None]             # (handle, first frame index, count) per block
+        self.n_alloc = self.n_done = 0
+
+    def _harvest(self, b):
+        if self.work[b] is None:
+            return
+        handle, first, count = self.work[b]
+        if handle is not None:
+            handle.wait()
+        if self.sink is not None and self.rank == self.dst:
+            srcs = self.recv[b] if self.world > 1 else [self.blocks[b]]
+            for r, t in enumerate(srcs):
+                for k in range(count):
+                    self.sink(r, first + k, t[k])
+        self.work[b] = None
+
+    def slot(self):
+        """Tensor the next frame must be written to (valid until that frame is submitted)."""
+        b = (self.n_alloc // self.block) % 2
+        if self.n_alloc % self.block == 0:
+            self._harvest(b)                 # the gather that last used this block has to be done
+        t = self.blocks[b][self.n_alloc % self.block]
+        self.n_alloc += 1
+        return t
+
+    def _launch(self, b, first, count):
+        handle = None
+        if self.world > 1:
+            handle = dist.gather(self.blocks[b], self.recv[b], dst=self.dst, async_op=True)
+        self.work[b] = (handle, first, count)
+
+    def submit(self):
+        """The oldest slot handed out by slot() now holds a finished frame."""
+        self.n_done += 1
+        assert self.n_done <= self.n_alloc
+        if self.n_done % self.block == 0:
+            self._launch(((self.n_done - 1) // self.block) % 2, self.n_done - self.block, self.block)
+
+    def flush(self):
+        """Gather a partly filled last block and wait for everything outstanding."""
+        assert self.n_done == self.n_alloc, 'every slot must be submitted before flush()'
+        rem = self.n_done % self.block
+        cur = (self.n_done // self.block) % 2
+        if rem:
+            self._launch(cur, self.n_done - rem, rem)
+        self._harvest(cur ^ 1)
+        self._harvest(cur)
+        self.n_alloc = self.n_done = 0
+
+
+def run_frame_loop(queue_frame, nframes, depth=2, gather=None, stage=None):
+    """
+    The render loop of main.py:64-76 — queue frame k+1, then wait for frame k — with ``depth``
+    frames queued ahead of the one being waited for, and the finished frames handed to a
+    FrameGather.  ``queue_frame(slot)`` queues one frame and returns ``(evt, h_out)`` (``slot``:
+    the tensor the frame should be rendered into, or None); ``stage(slot, h_out)`` copies a host
+    frame into its slot when frames are not rendered into it directly (CPU collectives).
+    Returns the number of frames completed.
+    """
+    pending = []
+
+    def finish(item):
+        (evt, h_out), slot = item
+        evt.synchronize()
+        if gather is not None:
+            if stage is not None:
+                stage(slot, h_out)
+            gather.submit()
+
+    for _ in range(nframes):
+        slot = gather.slot() if gather is not None else None
+        pending.append((queue_frame(slot), slot))
+        if len(pending) > depth:
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
+    if gather is not None:
+        gather.flush()
+    return nframes
+
+
 def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

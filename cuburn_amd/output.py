@@ -21,10 +21,13 @@ class Output(object):
     def convert(self, fb, gprof, dim, stream=None):
         """Conversion and copy are one call here; kept for interface parity (output.py:29-37)."""
 
-    def copy(self, fb, dim, pool=None, stream=None):
-        """Queue dither+convert and the async D2H; returns the host array (output.py:85-88)."""
-        h_out = fb.host_buffer((dim.h, dim.w, 4), self.dtype)
-        _lib.check(_lib.load().fl_output(fb.ctx, dim.w, dim.h, self.fmt, h_out.ctypes.data, 0))
+    def copy(self, fb, dim, pool=None, stream=None, dev_out=0, host=True):
+        """Queue dither+convert and the async D2H; returns the host array (output.py:85-88).
+        ``dev_out``: device address that receives the converted frame instead of the context's own
+        pixel buffer (e.g. a tensor that RCCL gathers: no host round trip); ``host=False`` skips the
+        D2H copy altogether (returns None)."""
+        h_out = fb.host_buffer((dim.h, dim.w, 4), self.dtype) if host else None
+        _lib.check(_lib.load().fl_output(fb.ctx, dim.w, dim.h, self.fmt, h_out.ctypes.data if host else None, int(dev_out)))
         return h_out
 
     def encode(self, buf):

@@ -256,16 +256,22 @@ class RenderManager(object):
         self.last_nsamples = 0
 
     def _copy(self, rdr, gnm):
-        """Upload packed splines and palettes (cuburn/render.py:264-285)."""
-        times, knots = rdr.packer.pack(gnm)
+        """Upload packed splines and palettes (cuburn/render.py:264-285).  Skipped when the device
+        copy of this Renderer's genome handle already holds exactly these values."""
+        g = rdr._handle(self.fb)
+        sig = (rdr.packer.signature(gnm), tuple(tuple(v) for v in gnm['palette']))
+        if getattr(rdr, '_uploaded', None) == (rdr._mod_key, sig):
+            return
+        times, knots = rdr.packer.pack(gnm, sig=sig[0])
         palsrc = dict([(v[0], palette_decode(v[1:])) for v in gnm['palette']])
         ptimes, pvals = zip(*sorted(palsrc.items()))
         palettes = np.ascontiguousarray(np.array(pvals, dtype=np.float32))
         palette_times = np.full(32, 1e9, dtype=np.float32)
         palette_times[:len(ptimes)] = ptimes
-        _lib.check(_lib.load().fl_genome_upload(self.fb.ctx, rdr._handle(self.fb), times.ctypes.data,
+        _lib.check(_lib.load().fl_genome_upload(self.fb.ctx, g, times.ctypes.data,
                                                 knots.ctypes.data, palettes.ctypes.data,
                                                 palette_times.ctypes.data, len(ptimes)))
+        rdr._uploaded = (rdr._mod_key, sig)
 
     def resolve_accum_mode(self, dim):
         mode = self.accum_mode
@@ -275,9 +281,10 @@ class RenderManager(object):
             mode = _lib.ACCUM_BINNED if ntiles <= 8191 else _lib.ACCUM_ATOMIC
         return mode
 
-    def queue_frame(self, rdr, gnm, gprof, tc, copy=True):
+    def queue_frame(self, rdr, gnm, gprof, tc, copy=True, dev_out=0, host=True):
         """
         Queue one frame at centre time ``tc``; returns ``(evt, h_out)`` (render.py:374-434).
+        ``dev_out`` / ``host``: see Output.copy (frame straight into a device buffer of the caller).
         """
         lib = _lib.load()
         dim = self.fb.set_dim(gprof.width, gprof.height)
@@ -298,7 +305,7 @@ class RenderManager(object):
             params = getattr(gprof.filters, filt.name)
             filt.apply(self.fb, gprof, params, dim, tc)
         rdr.out.convert(self.fb, gprof, dim)
-        h_out = rdr.out.copy(self.fb, dim)
+        h_out = rdr.out.copy(self.fb, dim, dev_out=dev_out, host=host)
         return DurationEvent(self.fb, fid.value), h_out
 
     def timings_reset(self):
@@ -308,4 +315,7 @@ class RenderManager(object):
         """HIP-event times (ms) of the iterate, drain and filter kernels since timings_reset()."""
         it, fl, ft, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
         _lib.check(_lib.load().fl_timings(self.fb.ctx, C.byref(it), C.byref(fl), C.byref(ft), C.byref(n)))
-        return dict(iter_ms=it.value, flush_ms=fl.value, filter_ms=ft.value, launches=n.value)
+        d = (C.c_float * 6)()
+        _lib.check(_lib.load().fl_timings_detail(self.fb.ctx, C.byref(d)))
+        return dict(iter_ms=it.value, flush_ms=fl.value, filter_ms=ft.value, launches=n.value,
+                    accum_ms=d[1], flush_only_ms=d[2], de_ms=d[4], de_finish_ms=d[5])

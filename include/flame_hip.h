@@ -13,8 +13,10 @@
 #ifndef FLAME_HIP_H
 #define FLAME_HIP_H
 
+#ifndef __HIPCC_RTC__      /* hipRTC (run-time specialised iterate kernel) has no system headers; the includer typedefs */
 #include <stdint.h>
 #include <stddef.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -218,6 +220,10 @@ void fl_host_free(void *p);
  * (tile accumulate + flush); filter kernels; number of iterate launches.  Both calls sync. */
 int fl_timings_reset(fl_ctx *ctx);
 int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *niter_launches);
+/* The same, split further: ms[0] iterate kernels, [1] tile accumulate, [2] flush, [3] all fl_filter calls,
+ * [4] the DE proper (normalise + 8 directions of FL_FILT_BILATERAL), [5] the call that un-normalised the DE result
+ * (with logscale / colorclip riding along when they follow directly). */
+int fl_timings_detail(fl_ctx *ctx, float ms[6]);
 
 /* ---- debug taps (tests only): read/write device state ---- */
 enum {
@@ -254,6 +260,11 @@ int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
 /* Xform tap: apply xform `xfi` (nxf = the final xform) of temporal sample `ts` once to n points
  * {x, y, color, unused} with one RNG state each; results overwrite the inputs. */
 int fl_debug_apply_xf(fl_ctx *ctx, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng);
+/* Compile (only) the iterate kernel specialised for a genome structure, as fl_iterate does on a genome's
+ * first launch — the counterpart of cuburn/render.py:232-236 Renderer.compile.  Needs libhiprtc but no
+ * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8, acc = 0 (atomic), 1 / 3 (binned narrow / wide). */
+int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
+                         char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
 int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
 

@@ -198,3 +198,25 @@ def test_cli_print_blended_animation(tmp_path, capsys):
     assert text == gold['json_text']['A/full'] + '\n'
     assert cli.main(['A', '-d', str(tmp_path), '--print', '--half']) == 0
     assert capsys.readouterr().out == gold['json_text']['A/half'] + '\n'
+
+
+@pytest.mark.parametrize('cfg', ['cfg1', 'cfg2', 'cfg3', 'cfg5'])
+def test_per_genome_kernel_compiles(built, cfg):
+    """The iterate kernel specialised for a genome's structure (hipRTC, csrc/rtc.hip) compiles for
+    gfx950 for every BASELINE genome, both walker geometries and all accumulate modes.  hipRTC
+    needs no GPU; the same entry point runs on a genome's first launch on the device."""
+    import ctypes as C
+    import numpy as np
+    from cuburn_amd import _lib, configs
+    from cuburn_amd.packer import GenomePacker
+    lib = _lib.load()
+    gnm, prof = configs.CONFIGS[cfg]()
+    pk = GenomePacker(gnm)
+    prog = np.ascontiguousarray(pk.prog, np.int32)
+    ops = np.ascontiguousarray(pk.ops_array, np.int32)
+    log = C.create_string_buffer(8192)
+    for nw, count, acc in ((4, 0, 1), (4, 1, 0), (8, 0, 3), (8, 1, 1)):
+        rc = lib.fl_rtc_compile_check(prog.ctypes.data, len(prog), ops.ctypes.data, len(ops), nw, count, acc, log, len(log))
+        if rc == _lib.FL_E_UNSUPPORTED:
+            pytest.skip('libhiprtc is not installed')
+        assert rc == 0, log.value.decode()[:3000]

@@ -112,3 +112,110 @@ def test_sample_share_and_rank_seed():
             assert sum(shares) == n and max(shares) - min(shares) <= 1
     assert D.rank_seed(42, 0) == 42 and D.rank_seed(None, 0) == 42
     assert len({D.rank_seed(42, r) for r in range(8)}) == 8
+
+
+LOOP_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from cuburn_amd import distributed as D
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
+                            rank=int(os.environ['RANK']), world_size=2)
+    rank = dist.get_rank()
+
+    class Evt(object):                      # stands in for DurationEvent
+        def __init__(self, log, i): self.log, self.i = log, i
+        def synchronize(self): self.log.append(('done', self.i)); return self
+
+    for nframes, block, depth in ((11, 4, 2), (3, 4, 1), (8, 4, 3), (9, 2, 2)):
+        got, log, count = {}, [], [0]
+        def sink(r, index, frame):
+            got[(r, index)] = frame.clone()
+        g = D.FrameGather((3, 5, 4), torch.uint8, torch.device('cpu'), block=block, sink=sink)
+        def queue(slot):
+            i = count[0]; count[0] += 1
+            log.append(('queue', i))
+            frame = np.full((3, 5, 4), (17 * i + 5 * rank + 1) %% 251, np.uint8)     # what the device would render
+            return (Evt(log, i), frame)
+        def stage(slot, h_out):
+            slot.copy_(torch.from_numpy(h_out))
+        assert D.run_frame_loop(queue, nframes, depth=depth, gather=g, stage=stage) == nframes
+        # the loop keeps `depth` frames queued ahead of the one it waits for
+        for k in range(nframes - depth):
+            assert log.index(('queue', k + depth)) < log.index(('done', k)) < log.index(('queue', k + depth + 1)) if k + depth + 1 < nframes else True
+        if rank == 0:
+            assert sorted(got) == [(r, i) for r in range(2) for i in range(nframes)], sorted(got)
+            for (r, i), f in got.items():
+                assert f.shape == (3, 5, 4) and int(f[0, 0, 0]) == (17 * i + 5 * r + 1) %% 251, (r, i)
+        else:
+            assert not got
+        dist.barrier()
+    if rank == 0:
+        print('LOOP_OK')
+    dist.destroy_process_group()
+''') % REPO
+
+
+def test_bench_frame_loop_and_block_gather_world2(tmp_path):
+    """bench.py's own loop (distributed.run_frame_loop + FrameGather: frames queued ahead, one
+    asynchronous gather per block of frames, partial last block, two alternating blocks) with two
+    ranks on gloo: rank 0 receives every frame of every rank, in order, exactly once."""
+    script = tmp_path / 'worker.py'
+    script.write_text(LOOP_WORKER)
+    port = str(29300 + os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'LOOP_OK' in outs[0]
+
+
+def test_frame_gather_single_process():
+    """Without a process group the gather is the identity: the sink sees this rank's frames."""
+    import torch
+    from cuburn_amd import distributed as D
+    got = []
+    g = D.FrameGather((2, 2, 4), torch.uint8, torch.device('cpu'), block=3, sink=lambda r, i, f: got.append((r, i, int(f[0, 0, 0]))))
+    for i in range(7):
+        g.slot().fill_(i + 1)
+        g.submit()
+    g.flush()
+    assert got == [(0, i, i + 1) for i in range(7)]
+
+
+EMPTY_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from cuburn_amd import distributed as D
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
+                            rank=int(os.environ['RANK']), world_size=2)
+    rank = dist.get_rank()
+    mine = D.shard(range(1))                      # one frame, two ranks: rank 1 has nothing
+    frames = [torch.full((2, 3, 4), 7, dtype=torch.uint8) for _ in mine]
+    anim = D.gather_animation(frames, 1, dst=0)
+    if rank == 0:
+        assert len(anim) == 1 and int(anim[0][0, 0, 0]) == 7
+        print('EMPTY_OK')
+    dist.barrier()
+    dist.destroy_process_group()
+''') % REPO
+
+
+def test_gather_animation_with_an_empty_shard(tmp_path):
+    """Fewer frames than ranks: the rank without a frame still takes part in the collective
+    (it used to raise on zeros_like(None) while the others blocked inside the gather)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(EMPTY_WORKER)
+    port = str(29100 + os.getpid() % 150)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'EMPTY_OK' in outs[0]

@@ -257,6 +257,47 @@ def test_temporal_samples_equally_weighted(built):
     m.fb.free()
 
 
+@pytest.mark.parametrize('which', ['linear', 'cfg3', 'cfg5'])
+def test_per_genome_kernel_equals_interpreter(built, which, monkeypatch, capfd):
+    """fl_iterate runs a kernel compiled for the genome's structure (hipRTC, the counterpart of the
+    reference's per-genome CUDA module, render.py:232-236); FLAME_RTC=0 runs the precompiled
+    interpreter kernel.  Same arithmetic in the same order: packed histograms, sample counters,
+    RNG states and walker points must agree bit for bit — with hardware transcendentals too —
+    in both accumulate modes."""
+    if which == 'linear':
+        gnm, prof = animated_linear_flame()
+    else:
+        gnm, prof = small(configs.CONFIGS[which], 640, 360)
+        gnm['camera']['scale'] = 1.0 if which == 'cfg3' else 0.8
+    out = {}
+    for rtc in ('0', '1'):
+        monkeypatch.setenv('FLAME_RTC', rtc)
+        m = render.RenderManager(device=0, host_seed=42)            # production geometry
+        for mode in (0, 1):
+            lib = _lib.load()
+            rdr, gprof, dim, g, ts, td = setup_frame(m, gnm, prof, 0.4)
+            nbins = dim.ah * dim.astride
+            _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 1))
+            _lib.check(lib.fl_debug_iter_launch(m.fb.ctx, g, dim.w, dim.h, 0, 24, 5, mode))
+            ctr = np.zeros(4, np.uint64)
+            _lib.check(lib.fl_debug_counters(m.fb.ctx, ctr.ctypes.data))
+            _lib.check(lib.fl_debug_flush(m.fb.ctx, dim.w, dim.h))
+            out[rtc, mode] = dict(ctr=ctr, front=m.fb.read('front', (nbins, 4), np.float32),
+                                  rng=m.fb.read('seeds', (m.fb.nwalkers, 3), np.uint32),
+                                  pts=m.fb.read('points', (m.fb.nslots * m.fb.nthreads, 4), np.float32))
+        m.fb.free()
+    assert 'interpreter kernel' not in capfd.readouterr().err, 'the per-genome kernel was not used'
+    for mode in (0, 1):
+        a, b = out['0', mode], out['1', mode]
+        assert int(a['ctr'][0]) > 100000
+        assert np.array_equal(a['ctr'], b['ctr']), (which, mode, a['ctr'], b['ctr'])
+        assert np.array_equal(a['rng'], b['rng']), (which, mode)
+        assert np.array_equal(a['pts'].view(np.uint32), b['pts'].view(np.uint32)), (which, mode)
+        assert np.array_equal(a['front'][:, 3], b['front'][:, 3]), (which, mode)
+        if mode == 1 or int(a['ctr'][3]) == 0:          # (drains of full cells regroup float adds in atomic mode)
+            assert np.array_equal(a['front'].view(np.uint32), b['front'].view(np.uint32)), (which, mode)
+
+
 def hot_flame():
     """The transcendental-free flame plus a strongly contracting xform: a ~100-pixel region that
     takes 3 % of all samples."""
