@@ -219,3 +219,59 @@ def test_gather_animation_with_an_empty_shard(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'EMPTY_OK' in outs[0]
+
+
+CFG4_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from cuburn_amd import distributed as D, configs, profile
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
+                            rank=int(os.environ['RANK']), world_size=2)
+    rank, world = dist.get_rank(), 2
+    gnm, prof = configs.cfg4()
+    gprof = profile.wrap(prof, gnm)
+    frames = profile.enumerate_times(gprof)                 # the 60 frames of BASELINE configs[3]
+    assert len(frames) == 60 and frames[0][0] == 1 and frames[-1][0] == 60
+    mine = D.shard(frames)                                   # rank r renders frames r+1, r+1+world, ...
+    assert [f[0] for f in mine] == list(range(rank + 1, 61, world))
+    td = gprof.frame_width(0.5) / round(gprof.fps * gprof.duration)
+    assert abs(td - 1.0 / 60) < 1e-12
+    got = {}
+    g = D.FrameGather((2, 4, 4), torch.uint8, torch.device('cpu'), block=4,
+                      sink=lambda r, i, f: got.__setitem__(r + i * world + 1, (int(f[0, 0, 0]), int(f[0, 0, 1]))))
+    it = iter(mine)
+    class Evt(object):
+        def synchronize(self): return self
+    def queue(slot):                                         # stands in for queue_frame: a frame that encodes its number and time
+        no, (tc,) = next(it)
+        slot[...] = 0
+        slot[0, 0, 0] = no
+        slot[0, 0, 1] = int(round(float(tc) * 120))
+        return (Evt(), None)
+    D.run_frame_loop(queue, len(mine), depth=2, gather=g)
+    if rank == 0:
+        assert sorted(got) == list(range(1, 61))
+        for no, (a, b) in got.items():
+            assert a == no and b == 2 * no - 1, (no, a, b)    # centre time (no - 0.5) / 60
+        print('CFG4_OK')
+    dist.barrier()
+    dist.destroy_process_group()
+''') % REPO
+
+
+def test_cfg4_sixty_frames_shard_and_gather_world2(tmp_path):
+    """BASELINE configs[3] bookkeeping with two ranks: the profile yields 60 frames, rank r takes
+    frames r+1, r+3, ...; every frame passes through the block-wise gather and arrives on rank 0
+    under its own frame number with its own centre time."""
+    script = tmp_path / 'worker.py'
+    script.write_text(CFG4_WORKER)
+    port = str(29450 + os.getpid() % 100)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'CFG4_OK' in outs[0]
