@@ -159,135 +159,6 @@ template <int PATTERN> __host__ __device__ __forceinline__ constexpr int tap_dy(
     return (v % 2 == 0) ? v / 2 : ((v - 1) / 2 % 2 == 0 ? (v - 1) / 2 : (v + 1) / 2);
 }
 
-__global__ void __launch_bounds__(256)
-k_de_prep(fl_dim d, float4 *__restrict__ N, float *__restrict__ Pw, const float4 *__restrict__ src, float dpow)
-{
-    PIX_IDX(d);
-    const float4 p = src[gi];
-    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
-    N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
-    Pw[gi] = fpow(p.w, dpow);
-}
-
-__global__ void __launch_bounds__(256)
-k_de_finish(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ N)
-{
-    PIX_IDX(d);
-    const float4 n = N[gi];
-    dst[gi] = make_float4(n.x * n.w, n.y * n.w, n.z * n.w, n.w);
-}
-
-// Tap addressing.  Interior blocks: the tap offset dy*astride+dx is wave-uniform, so it is folded
-// into the (scalar) base pointer and every load uses the same 32-bit lane offset.  Edge blocks
-// clamp per lane (cuburn/code/filters.py:22-35 reads through a clamping texture).
-// Measured alternatives on MI355X (1080p, per direction): this fully unrolled form 82-96 us
-// (~230 VGPR, 2 waves/SIMD, ~90 loads in flight per wave); rolled 4-tap chunks at 8 waves/SIMD
-// 118-129 us; raw buffer loads with scalar offsets 142-160 us.  The floor of this gather
-// structure is the L1/TA rate (776 B per pixel through a 64 B/clk/CU port ~ 49 us).
-template <int PATTERN, bool EDGE, typename T>
-__device__ __forceinline__ T tap_load(const fl_dim &d, const T *__restrict__ buf, int xi, int yi, uint32_t gi, int r)
-{
-    const int dx = tap_dx<PATTERN>(r), dy = tap_dy<PATTERN>(r);
-    if (!EDGE) {
-        const T *__restrict__ shifted = buf + (dy * (int)d.astride + dx);     // uniform
-        return shifted[gi];
-    }
-    const int xs = min(max(xi + dx, 0), (int)d.astride - 1), ys = min(max(yi + dy, 0), (int)d.ah - 1);
-    return buf[(uint32_t)(ys * (int)d.astride + xs)];
-}
-
-template <int PATTERN, bool EDGE>
-__device__ __forceinline__ void de_taps(const fl_dim &d, int xi, int yi, uint32_t gi,
-                                        const float4 *__restrict__ N, const float *__restrict__ Pw,
-                                        const float *__restrict__ RA, const float *spa,
-                                        float cs2, float ds, float gs, float4 &out, float &weightsum)
-{
-    const float4 cen = N[gi];
-    // the reference normalises the centre with 1/(w + 1e-6) and the taps with 1/w
-    const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
-    const float cx = cen.x * cfix, cy = cen.y * cfix, cz = cen.z * cfix;
-    const float cpow = Pw[gi];
-    const bool cen_live = cen.w > 0.0f;
-    float wprev = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, -16).w;
-    float4 pix = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, -15);
-#pragma unroll
-    for (int r0 = -15; r0 <= 15; r0 += 8) {
-        float4 nx[8];
-        float pw[8], ra[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = r0 + k;
-            if (r <= 15) {
-                nx[k] = tap_load<PATTERN, EDGE>(d, N, xi, yi, gi, r + 1);
-                pw[k] = tap_load<PATTERN, EDGE>(d, Pw, xi, yi, gi, r);
-                ra[k] = tap_load<PATTERN, EDGE>(d, RA, xi, yi, gi, r);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = r0 + k;
-            if (r <= 15) {
-                const float yd = pix.x - cx, ud = pix.y - cy, vd = pix.z - cz;
-                float cdiff = yd * yd + ud * ud + vd * vd;
-                cdiff = (pix.w > 0.0f && cen_live) ? cdiff : 0.5f;
-                float e = cs2 * cdiff + ds * fabsf(cpow - pw[k]);
-                if (r != 0) {
-                    const float g = (nx[k].w - wprev) * ra[k];
-                    e -= fexp2(r < 0 ? -gs * g : gs * g);
-                }
-                const float factor = spa[r < 0 ? -r : r] * fexp2(e);
-                weightsum += factor;
-                const float fw = factor * pix.w;
-                out.x += fw * pix.x; out.y += fw * pix.y; out.z += fw * pix.z; out.w += fw;
-                wprev = pix.w;
-                pix = nx[k];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int PATTERN>
-__global__ void __launch_bounds__(256)
-k_de_bilateral(fl_dim d, float4 *__restrict__ Nout, float *__restrict__ Pout,
-               const float4 *__restrict__ N, const float *__restrict__ Pw, const float *__restrict__ RA,
-               float sstd, float cstd, float dstd, float dpow, float gspeed)
-{
-    PIX_IDX(d);
-    __shared__ float spa[16];
-    const int lt = threadIdx.y * blockDim.x + threadIdx.x;
-    if (lt < 16) { const float df = (float)lt; spa[lt] = fexp(fdiv(df * df, -FM_SQRT2 * sstd)); }
-    const float cs2 = frcp(-FM_SQRT2 * 3.0f * cstd) * FM_LOG2E;       // exp(c*x) = exp2(c*log2e*x)
-    const float ds = fdiv(-0.5f, dstd);
-    __syncthreads();
-    float4 out = make_float4(0, 0, 0, 0);
-    float weightsum = 0.0f;
-    // block-uniform: blocks whose taps stay inside the buffer skip the clamps
-    const int bx0 = blockIdx.x * blockDim.x, by0 = blockIdx.y * blockDim.y;
-    const bool interior = bx0 >= 17 && bx0 + (int)blockDim.x + 17 <= (int)d.astride &&
-                          by0 >= 17 && by0 + (int)blockDim.y + 17 <= (int)d.ah;
-    if (interior) de_taps<PATTERN, false>(d, xi, yi, (uint32_t)gi, N, Pw, RA, spa, cs2, ds, gspeed, out, weightsum);
-    else de_taps<PATTERN, true>(d, xi, yi, (uint32_t)gi, N, Pw, RA, spa, cs2, ds, gspeed, out, weightsum);
-    // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the 1/weightsum
-    // of the reference cancels), the density is out.w / (weightsum + 1e-10)
-    const float wn = out.w * frcp(weightsum + 1e-10f);
-    const float rn = out.w >= 1.17549435e-38f ? frcp(out.w) : 0.0f;   // v_rcp_f32 of a denormal is +inf
-    Nout[gi] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
-    Pout[gi] = fpow(wn, dpow);
-}
-
-// second density blur writing 1/(avg + 1e-6) (cuburn/code/filters.py:120-131 + :247)
-__global__ void __launch_bounds__(256)
-k_den_blur_1c_rcp(fl_dim d, float *__restrict__ dst, const float *__restrict__ src, int pattern, int upsample, Coefs7 k) {
-    PIX_IDX(d);
-    const float2 pat = shear_patterns[pattern];
-    float den = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-        den += src[shear_idx(d, pat, xi, yi, (float)((i - 3) * (1 << upsample)))] * k.c[i];
-    dst[gi] = frcp(den + 1.0e-6f);
-}
-
 // ---------------------------------------------------------------------------------------------
 // LDS-tiled DE pass.  A workgroup owns a 32x16 output tile; it stages the tile plus the halo its
 // taps can reach (|dx| <= HX, |dy| <= HY, compile-time per direction) of N (float4) and of the
@@ -310,112 +181,6 @@ template <int PATTERN> __host__ __device__ __forceinline__ constexpr int de_hy()
     int m = 0;
     for (int r = -16; r <= 16; ++r) { int v = tap_dy<PATTERN>(r); v = v < 0 ? -v : v; m = v > m ? v : m; }
     return m;
-}
-
-template <int PATTERN>
-__global__ void __launch_bounds__(256)
-k_de_bilateral_lds(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRout, float *__restrict__ Wout,
-                   const float4 *__restrict__ N, const float2 *__restrict__ PR,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed)
-{
-    constexpr int HX = de_hx<PATTERN>(), HY = de_hy<PATTERN>();
-    constexpr int LW = DE_TW + 2 * HX, LH = DE_TH + 2 * HY;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *sN = reinterpret_cast<float4 *>(smem);                       // [LH][LW]
-    float2 *sPR = reinterpret_cast<float2 *>(smem + LH * LW * 16);       // [LH][LW]
-    float *spa = reinterpret_cast<float *>(smem + LH * LW * 24);         // [16]
-
-    const int tid = threadIdx.x;
-    const int bx0 = blockIdx.x * DE_TW, by0 = blockIdx.y * DE_TH;
-    (void)spa;
-    // staging: all global loads of the tile are issued before the first LDS store (a rolled loop
-    // serialises one HBM/L2 round trip per iteration and made this kernel latency bound)
-    constexpr int NIT = (LH * LW + 255) / 256;
-    float4 tn[NIT];
-    float2 tp[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = min(it * 256 + tid, LH * LW - 1);
-        const int ly = idx / LW, lx = idx - ly * LW;
-        const int gx = min(max(bx0 + lx - HX, 0), (int)d.astride - 1);
-        const int gy = min(max(by0 + ly - HY, 0), (int)d.ah - 1);
-        const uint32_t g = (uint32_t)(gy * (int)d.astride + gx);
-        tn[it] = N[g];
-        tp[it] = PR[g];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid;
-        if (idx < LH * LW) { sN[idx] = tn[it]; sPR[idx] = tp[it]; }
-    }
-    const float cs2 = frcp(-FM_SQRT2 * 3.0f * cstd) * FM_LOG2E;       // exp(c*x) = exp2(c*log2e*x)
-    const float ds = fdiv(-0.5f, dstd);
-    __syncthreads();
-
-    // spatial coefficients as wave-uniform scalars (compile-time indexed after unrolling)
-    float spk[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float df = (float)k;
-        spk[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fexp(fdiv(df * df, -FM_SQRT2 * sstd)))));
-    }
-
-    for (int half = 0; half < 2; ++half) {
-        const int ox = tid & 31, oy = (tid >> 5) + half * 8;
-        const int ci = (oy + HY) * LW + ox + HX;
-#define LN(r) sN[ci + tap_dy<PATTERN>(r) * LW + tap_dx<PATTERN>(r)]
-#define LP(r) sPR[ci + tap_dy<PATTERN>(r) * LW + tap_dx<PATTERN>(r)]
-        const float4 cen = sN[ci];
-        // the reference normalises the centre with 1/(w + 1e-6) and the taps with 1/w
-        const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
-        const float cx = cen.x * cfix, cy = cen.y * cfix, cz = cen.z * cfix;
-        const float cpow = sPR[ci].x;
-        const bool cen_live = cen.w > 0.0f;
-        float4 out = make_float4(0, 0, 0, 0);
-        float weightsum = 0.0f;
-        float wprev = LN(-16).w;
-        float4 pix = LN(-15);
-        // fully unrolled (tap offsets are ds_read immediates); the scheduling barrier every
-        // DE_GROUP taps keeps the compiler from hoisting all 64 LDS reads (215 VGPRs otherwise)
-#pragma unroll
-        for (int r0 = -15; r0 <= 15; r0 += DE_GROUP) {
-            float4 nx[DE_GROUP];
-            float2 pr[DE_GROUP];
-#pragma unroll
-            for (int k = 0; k < DE_GROUP; ++k) if (r0 + k <= 15) { nx[k] = LN(r0 + k + 1); pr[k] = LP(r0 + k); }
-#pragma unroll
-            for (int k = 0; k < DE_GROUP; ++k) {
-                const int r = r0 + k;
-                if (r <= 15) {
-                    const float yd = pix.x - cx, ud = pix.y - cy, vd = pix.z - cz;
-                    float cdiff = yd * yd + ud * ud + vd * vd;
-                    cdiff = (pix.w > 0.0f && cen_live) ? cdiff : 0.5f;
-                    float e = cs2 * cdiff + ds * fabsf(cpow - pr[k].x);
-                    if (r != 0) {
-                        const float g = (nx[k].w - wprev) * pr[k].y;
-                        e -= fexp2(r < 0 ? -gspeed * g : gspeed * g);
-                    }
-                    const float factor = spk[r < 0 ? -r : r] * fexp2(e);
-                    weightsum += factor;
-                    const float fw = factor * pix.w;
-                    out.x += fw * pix.x; out.y += fw * pix.y; out.z += fw * pix.z; out.w += fw;
-                    wprev = pix.w;
-                    pix = nx[k];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef LN
-#undef LP
-        // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the
-        // 1/weightsum of the reference cancels), the density is out.w / (weightsum + 1e-10)
-        const float wn = out.w * frcp(weightsum + 1e-10f);
-        const float rn = out.w >= 1.17549435e-38f ? frcp(out.w) : 0.0f;   // v_rcp_f32 of a denormal is +inf
-        const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + bx0 + ox);
-        Nout[go] = make_float4(out.x * rn, out.y * rn, out.z * rn, wn);
-        PRout[go].x = fpow(wn, dpow);
-        Wout[go] = wn;              // density plane: input of the next direction's blurs
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -864,15 +629,6 @@ void launch_bilateral(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
                       float sstd, float cstd, float dstd, float dpow, float gspeed) {
     hipLaunchKernelGGL(k_bilateral, GRID(d), 0, st, d, dst, src, blur, pattern, radius, sstd, cstd, dstd, dpow, gspeed);
 }
-void launch_de_prep(hipStream_t st, fl_dim d, float4 *N, float *Pw, const float4 *src, float dpow) { hipLaunchKernelGGL(k_de_prep, GRID(d), 0, st, d, N, Pw, src, dpow); }
-void launch_de_finish(hipStream_t st, fl_dim d, float4 *dst, const float4 *N) { hipLaunchKernelGGL(k_de_finish, GRID(d), 0, st, d, dst, N); }
-void launch_den_blur_1c_rcp(hipStream_t st, fl_dim d, float *dst, const float *src, int p, int up, const float *c) { hipLaunchKernelGGL(k_den_blur_1c_rcp, GRID(d), 0, st, d, dst, src, p, up, mk(c)); }
-void launch_de_bilateral(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *Pout, const float4 *N, const float *Pw,
-                         const float *RA, float sstd, float cstd, float dstd, float dpow, float gspeed) {
-#define DE(P) case P: hipLaunchKernelGGL(k_de_bilateral<P>, GRID(d), 0, st, d, Nout, Pout, N, Pw, RA, sstd, cstd, dstd, dpow, gspeed); break
-    switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
-#undef DE
-}
 void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow) { hipLaunchKernelGGL(k_de_prep2, GRID(d), 0, st, d, N, (float2 *)PR, W, src, dpow); }
 void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *c) {
 #define DB(P) case P: hipLaunchKernelGGL(k_den_blur2_lds<P>, dim3((d.astride + DB_TW - 1) / DB_TW, d.ah / DB_TH), dim3(256), 0, st, d, (float2 *)PR, W, mk(c)); break
@@ -889,21 +645,9 @@ static void launch_de_pk_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRo
     hipLaunchKernelGGL(k_de_bilateral_pk<P>, dim3((d.astride + de_span<P>() + DE_TW - 1) / DE_TW, d.ah / DE_TH), dim3(256), lds, st,
                        d, Nout, PRout, Wout, N, PR, sstd, cstd, dstd, dpow, gspeed);
 }
-template <int P>
-static void launch_de_lds_one(hipStream_t st, fl_dim d, float4 *Nout, float2 *PRout, float *Wout, const float4 *N, const float2 *PR,
-                              float sstd, float cstd, float dstd, float dpow, float gspeed) {
-    constexpr int LW = DE_TW + 2 * de_hx<P>(), LH = DE_TH + 2 * de_hy<P>();
-    const size_t lds = (size_t)LW * LH * 24 + 64 + 33 * 4 + 12;
-    static unsigned long long attr = 0;
-    ensure_max_dynamic_lds((const void *)k_de_bilateral_lds<P>, attr);
-    hipLaunchKernelGGL(k_de_bilateral_lds<P>, dim3(d.astride / DE_TW, d.ah / DE_TH), dim3(256), lds, st, d, Nout, PRout, Wout, N, PR,
-                       sstd, cstd, dstd, dpow, gspeed);
-}
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
-                             float sstd, float cstd, float dstd, float dpow, float gspeed, bool pk) {
-    // pk: packed-math form (default); otherwise the scalar-math form (FLAME_DE_LDS_AOS=1 when the context was created)
-#define DE(P) case P: if (!pk) launch_de_lds_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); \
-                      else launch_de_pk_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
+                             float sstd, float cstd, float dstd, float dpow, float gspeed) {
+#define DE(P) case P: launch_de_pk_one<P>(st, d, Nout, (float2 *)PRout, Wout, N, (const float2 *)PR, sstd, cstd, dstd, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
 }

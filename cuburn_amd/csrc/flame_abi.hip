@@ -79,7 +79,7 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    bool env_bin_wide = false, env_de_reference = false, env_de_gather = false, env_de_aos = false, env_de_split = false;
+    bool env_bin_wide = false, env_de_reference = false, env_de_split = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
 };
 #define L(c) ((c)->lanes[(c)->cur])
@@ -220,10 +220,8 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
-    c->env_de_gather = env_on("FLAME_DE_GATHER");
-    c->env_de_aos = env_on("FLAME_DE_LDS_AOS");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
-    c->env_de_split = env_on("FLAME_DE_SPLIT") || c->env_de_aos;      // previous form: blur kernel + bilateral kernel per direction
+    c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
     // every failure below leaves through fl_ctx_destroy, which frees whatever exists so far
@@ -684,7 +682,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
-        if (L(c).pend_finish || c->env_de_reference || c->env_de_gather) flush_pending(c);
+        if (L(c).pend_finish || c->env_de_reference) flush_pending(c);
         if (c->env_de_reference) {         // the literal per-tap form of the reference kernel
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur(st, d, L(c).d_blur, L(c).d_front, pat, 0, k7);
@@ -694,7 +692,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             }
             break;
         }
-        if (!c->env_de_gather && !c->env_de_split) {
+        if (!c->env_de_split) {
             // One kernel per direction (de.hip): N ping-pongs between the back and front buffers
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
             launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
@@ -706,8 +704,8 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
             break;
         }
-        if (!c->env_de_gather) {
-            // LDS-tiled form: packed planes PR = (w^dpow, 1/(avg+1e-6)), ping-pong in the side buffer
+        {
+            // previous form (FLAME_DE_SPLIT=1): packed planes PR = (w^dpow, 1/(avg+1e-6)), ping-pong in the side buffer
             const size_t nb2 = (size_t)d.ah * d.astride;
             float *PRa = (float *)L(c).d_side, *PRb = PRa + 2 * nb2;
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
@@ -716,27 +714,13 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             else launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
             for (int pat = 0; pat < 8; ++pat) {
                 launch_den_blur2_lds(st, d, pat, PRa, L(c).d_blur, k7);
-                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4], !c->env_de_aos);
+                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb); std::swap(PRa, PRb);
             }
             // 8 swaps: the result sits normalised in Na == d_back; un-normalising it into d_front
             // is left pending so that a logscale / colorclip that follows can ride along
             L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
-            break;
         }
-        // planes carved from the float4 side buffer: RA = 1/(avg+1e-6), Pa / Pb = w^dpow ping-pong
-        const size_t nb = (size_t)d.ah * d.astride;
-        float *RA = (float *)L(c).d_side, *Pa = RA + nb, *Pb = Pa + nb;
-        float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-        launch_de_prep(st, d, Na, Pa, L(c).d_front, p[3]);          // front(x,y,z,w) -> Na, Pa
-        for (int pat = 0; pat < 8; ++pat) {
-            launch_den_blur(st, d, L(c).d_blur, Na, pat, 0, k7);
-            launch_den_blur_1c_rcp(st, d, RA, L(c).d_blur, pat, 1, k7);
-            launch_de_bilateral(st, d, pat, Nb, Pb, Na, Pa, RA, p[0], p[1], p[2], p[3], p[4]);
-            std::swap(Na, Nb); std::swap(Pa, Pb);
-        }
-        // 8 swaps: the result sits in Na == d_back; un-normalise it into d_front
-        launch_de_finish(st, d, L(c).d_front, Na);
     } break;
     case FL_FILT_LOGSCALE:
         REQUIRE(np >= 2, "logscale needs k1,k2");

@@ -69,17 +69,12 @@ void launch_den_blur_1c(hipStream_t st, fl_dim d, float *dst, const float *src, 
 void launch_full_blur(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, int pattern, int upsample, const float *coefs7);
 void launch_bilateral(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, const float *blur, int pattern,
                       int radius, float sstd, float cstd, float dstd, float dpow, float gspeed);
-void launch_de_prep(hipStream_t st, fl_dim d, float4 *N, float *Pw, const float4 *src, float dpow);
-void launch_de_finish(hipStream_t st, fl_dim d, float4 *dst, const float4 *N);
-void launch_den_blur_1c_rcp(hipStream_t st, fl_dim d, float *dst, const float *src, int pattern, int upsample, const float *coefs7);
-void launch_de_bilateral(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *Pout, const float4 *N, const float *Pw,
-                         const float *RA, float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
 void launch_yuv_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
 void launch_de_finish_tone(hipStream_t st, fl_dim d, float4 *dst, const float4 *N, bool do_log, float k1, float k2, bool do_clip, const float *cc5);
 void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *coefs7);
 void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
-                             float sstd, float cstd, float dstd, float dpow, float gspeed, bool packed);
+                             float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float highpow, float gam, float lin, float lingam);
 void launch_gamma_full_hi(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
