@@ -232,9 +232,25 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
     // Cumulative xform densities of this slot's temporal sample (constant for the launch), one
     // per lane: the wave-uniform choice is then ONE vector compare + find-first-set instead
-    // of a scalar compare chain.  Lanes past the last density hold 2.0 (never chosen first).
-    const float cdf_lane = ((int)l < nxf - 1 && l < 63u) ? P[cdf_off + (int)l] : 2.0f;
-    const float fa_stride = (float)astride - 0.5f, fa_height = (float)aheight - 0.5f;
+    // of a scalar compare chain.
+    // Lane l holds the selector threshold of xform l: the xform is chosen when
+    //     (float)sel * 2^-32 <= cdf[l]                                   (iter.py:260-272)
+    // The left side is a non-decreasing function of the 32-bit selector, so the condition is
+    // sel <= T_l with T_l the largest selector that satisfies it — found once per launch by
+    // bisection on exactly that float expression.  The per-round choice is then ONE integer
+    // compare against the (scalar) selector; lanes past the last density never match.
+    const float cdf_lane = ((int)l < nxf - 1 && l < 63u) ? P[cdf_off + (int)l] : -1.0f;
+    auto sel_ok = [&](uint32_t s) -> bool { return (float)s * (1.0f / 4294967296.0f) <= cdf_lane; };
+    const bool thr_valid = sel_ok(0u);
+    uint32_t thr = 0xffffffffu;
+    if (!sel_ok(thr)) {
+        uint32_t lo = 0u, hi = 0xffffffffu;             // sel_ok(lo) holds (where thr_valid), sel_ok(hi) does not
+        for (int it = 0; it < 32; ++it) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (sel_ok(mid)) lo = mid; else hi = mid;
+        }
+        thr = lo;
+    }
     // swap destinations of this and the next two rounds (phase = round % 3), rotated every round
     uint32_t rot0 = shuffle_dest<NW>(w, l, round0 % 3u), rot1 = shuffle_dest<NW>(w, l, (round0 + 1u) % 3u),
              rot2 = shuffle_dest<NW>(w, l, (round0 + 2u) % 3u);
@@ -245,9 +261,8 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     // selector of round r+1 is drawn at the top of round r, so the record it picks can be
     // fetched a whole round before it is needed.
     auto choose = [&](uint32_t sel) -> int {
-        const float xfsel = (float)sel * (1.0f / 4294967296.0f);
-        // smallest i with xfsel <= cdf[i]; nxf - 1 if there is none (iter.py:260-272)
-        const unsigned long long le = __ballot(xfsel <= cdf_lane) | (1ull << 63);
+        // smallest i with sel <= T_i; nxf - 1 if there is none
+        const unsigned long long le = __ballot(thr_valid && sel <= thr) | (1ull << 63);
         return min((int)__builtin_ctzll(le), nxf - 1);
     };
     uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
@@ -292,13 +307,15 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         const float cx = fmaf(cam0, fx, fmaf(cam1, fy, cam2));              // iter.py:306-309
         const float cy = fmaf(cam3, fx, fmaf(cam4, fy, cam5));
         // iter.py:313-317: round to nearest even, reject outside [0, astride) x [0, aheight).
-        // Done in the float domain (both limits are even, so x.5 ties round outward at the top
-        // and to 0 at the bottom): one compare chain instead of two saturating conversions.
-        bool ok = (cx >= -0.5f) & (cx < fa_stride) & (cy >= -0.5f) & (cy < fa_height);     // NaN -> false; '&': no short-circuit branches
-        // binned mode: a rejected sample only needs its tile number forced to "none" below, its
-        // coordinate bits are never looked at, so they are not masked here
-        const uint32_t ix = (uint32_t)(int)__builtin_rintf(ok || BINNED ? cx : 0.0f);
-        const uint32_t iy = (uint32_t)(int)__builtin_rintf(ok || BINNED ? cy : 0.0f);
+        // Adding 1.5 * 2^23 rounds to the nearest integer (ties to even) in the float adder and leaves
+        // that integer in the low mantissa bits: for every finite or non-finite cx the difference
+        // to the bit pattern of 1.5 * 2^23 is rint(cx) if that lies in [0, 2^22), and a value >= 2^22
+        // (as unsigned) otherwise — negative, huge, infinite and NaN inputs all fail the range test.
+        const uint32_t ix = __float_as_uint(cx + 12582912.0f) - 0x4b400000u;
+        const uint32_t iy = __float_as_uint(cy + 12582912.0f) - 0x4b400000u;
+        bool ok = (ix < astride) & (iy < aheight);
+        // (binned mode: a rejected sample only needs its tile number forced to "none" below, its
+        // coordinate bits are never looked at)
         if (COUNT) n_oob += !ok;
         const uint32_t gi = ok ? iy * astride + ix : 0u;
 
