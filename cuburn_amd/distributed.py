@@ -106,6 +106,11 @@ class FrameGather(object):
         handle, first, count = self.work[b]
         if handle is not None:
             handle.wait()
+            if self.blocks[b].is_cuda:
+                # Work.wait() on RCCL only makes torch's current stream wait; the frames are written
+                # by the render context's own streams, so the host has to know the gather is over
+                # before the block is handed out again (this is eight frames later: no stall)
+                torch.cuda.current_stream(self.blocks[b].device).synchronize()
         if self.sink is not None and self.rank == self.dst:
             srcs = self.recv[b] if self.world > 1 else [self.blocks[b]]
             for r, t in enumerate(srcs):

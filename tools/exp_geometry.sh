@@ -1,0 +1,12 @@
+#!/bin/bash
+# walker geometry sweep with the per-genome kernel: slots (workgroups resident per CU) x rounds per sorted batch
+run() { env "$@" python bench.py --steps 30 --warmup 5 --cpu-seconds 0 --preheat-seconds 1.5 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_frame']
+print('$*: %.3f ms/frame  [iter %.3f accum+flush %.3f filt %.3f]' % (d['ms_per_step'], k['iter'], k['accum_flush'], k['filters']))"; }
+run FLAME_NSLOTS=1536 FLAME_BIN_ROUNDS=16
+run FLAME_NSLOTS=1792 FLAME_BIN_ROUNDS=12
+run FLAME_NSLOTS=1792 FLAME_BIN_ROUNDS=13
+run FLAME_NSLOTS=2048 FLAME_BIN_ROUNDS=10
+run FLAME_NSLOTS=2048 FLAME_BIN_ROUNDS=8
+run FLAME_NSLOTS=1280 FLAME_BIN_ROUNDS=16
+run FLAME_NSLOTS=1536 FLAME_BIN_ROUNDS=14
