@@ -41,7 +41,6 @@
 #include "kernels.h"
 #include <utility>
 #include <cmath>
-#include <algorithm>
 
 struct DeCoefs { float k[7]; };
 struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
@@ -269,8 +268,7 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
 template <int P>
 __global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
 k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
-         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles,
-         uint32_t *__restrict__ tile_ctr)
+         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles)
 {
     using G = DeGeo<P>;
     static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
@@ -280,34 +278,17 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     float *sW = reinterpret_cast<float *>(sB);                   // prep: dense density plane ...
     float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
 
-    // Persistent workgroups (two per CU) pull tiles from per-XCD counters.  Every XCD owns a
-    // contiguous run of tiles in column-major order, so the tiles in flight on an XCD are vertical
-    // neighbours and find each other's halo rows in that XCD's L2; pulling instead of a fixed
-    // assignment removes the tail (2135 tiles over 512 slots = 4.2 rounds) and lets the workgroups
-    // of a CU drift out of phase, so that one stages while the other computes.  A workgroup whose
-    // own XCD has run dry takes tiles from the others: every tile is served whatever the
-    // placement of workgroups on XCDs (which HIP does not promise).
-    __shared__ uint32_t s_tile;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of
+    // tiles in column-major order, so that the tiles resident together on an XCD are vertical
+    // neighbours and find each other's halo rows in that XCD's L2.
     const uint32_t per_xcd = (ntiles + 7u) / 8u;
-    const uint32_t my_xcd = xcc_id();
-    const int tid0 = threadIdx.x;
-    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
-    for (uint32_t probe = 0; probe < 8u;) {
-    // The thread index passes through an opaque move every iteration: otherwise the compiler hoists
-    // the ~25 lane-constant staging / output indices out of the tile loop and spills them around it.
-    int tid;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(tid0));
-    const uint32_t xq = (my_xcd + probe) & 7u;
-    if (tid == 0) s_tile = atomicAdd(tile_ctr + xq, 1u);
-    __syncthreads();
-    const uint32_t kq = s_tile;
-    __syncthreads();                                   // s_tile and the LDS planes are free again
-    const uint32_t lo_t = xq * per_xcd;
-    if (lo_t >= ntiles || kq >= min(per_xcd, ntiles - lo_t)) { ++probe; continue; }
-    const uint32_t t = lo_t + kq;
+    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (t >= ntiles) return;
     const int tx = (int)(t / tiles_y), ty = (int)(t % tiles_y);
     // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
     const int bx0 = tx * G::TW - (G::K > 0 ? G::SPAN : 0), by0 = ty * G::TH;
+    const int tid = threadIdx.x;
+    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
     // does any staged position leave the image?  (block-uniform)
     const bool border = by0 - G::HU < 0 || by0 + G::TH + G::HU > (int)d.ah ||
                         bx0 + min(0, de_shear(P, -G::HU)) + min(0, de_shear(P, G::TH + G::HU)) - G::HV - 1 < 0 ||
@@ -425,7 +406,6 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     const int xo = bx0 + ((ou * G::K) >> 1) + ov, yo = by0 + ou;
     if (xo >= 0 && xo <= xmax && yo <= ymax)                        // the parallelogram sticks out of the image at both ends of a band
         Nout[(uint32_t)(yo * (int)d.astride + xo)] = res;
-    }   // tile loop
 }
 
 // Normalise the accumulator into N (first pass input); with YUV -> RGB in front when the chain starts with `yuv`
@@ -447,7 +427,7 @@ __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__rest
 
 template <int P>
 static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
-                              float cs2, float ads, float dpow, float gspeed, uint32_t *tile_ctr)
+                              float cs2, float ads, float dpow, float gspeed)
 {
     using G = DeGeo<P>;
     static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
@@ -455,19 +435,12 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
     ensure_max_dynamic_lds((const void *)k_de_dir<P>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
-    int dev = 0, ncu = 256;
-    static int ncu_of[64] = {};
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        if (!ncu_of[dev]) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, dev) == hipSuccess) ncu_of[dev] = p.multiProcessorCount; }
-        if (ncu_of[dev]) ncu = ncu_of[dev];
-    }
-    const uint32_t nwg = std::min<uint32_t>(2u * (uint32_t)ncu, ntiles);          // two resident workgroups per CU
-    hipLaunchKernelGGL(k_de_dir<P>, dim3(nwg), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
-                       cs2, ads, dpow, gspeed, tiles_y, ntiles, tile_ctr);
+    hipLaunchKernelGGL(k_de_dir<P>, dim3(8 * ((ntiles + 7) / 8)), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
+                       cs2, ads, dpow, gspeed, tiles_y, ntiles);
 }
 
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, uint32_t *tile_ctr)
+                   float sstd, float cstd, float dstd, float dpow, float gspeed)
 {
     DeCoefs kc;
     for (int i = 0; i < 7; ++i) kc.k[i] = coefs7[i];
@@ -476,7 +449,7 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     for (int r = 0; r < 16; ++r) spk.s[r] = expf((float)(r * r) / (-1.41421353816986f * sstd));
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
-#define DE(P) case P: launch_de_dir_one<P>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tile_ctr + 8 * P); break
+#define DE(P) case P: launch_de_dir_one<P>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed); break
     switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
 #undef DE
 }

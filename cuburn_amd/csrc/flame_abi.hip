@@ -46,7 +46,6 @@ struct Lane {
     float *d_params = nullptr;        // [nslots * pstride] one block per temporal sample = per walker slot (grow-only)
     size_t params_floats = 0;
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
-    uint32_t *d_de_ctr = nullptr;     // [8 directions][8 XCDs] tile counters of the DE's persistent workgroups
     // cross-lane ordering of the state both lanes share
     hipEvent_t ev_interp_done = nullptr;   // genome staging buffers + palette RNG states
     hipEvent_t ev_iter_done = nullptr;     // walkers + their RNG states
@@ -238,7 +237,6 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
         for (int i = 0; i < c->nlanes && e == hipSuccess; ++i) {
             Lane &ln = c->lanes[i];
             if ((e = hipMalloc(&ln.d_palette, sizeof(u64) * FL_PAL_H * FL_PAL_W))) break;
-            if ((e = hipMalloc(&ln.d_de_ctr, 64 * sizeof(uint32_t)))) break;
             if ((e = hipEventCreateWithFlags(&ln.ev_interp_done, hipEventDisableTiming))) break;
             if ((e = hipEventCreateWithFlags(&ln.ev_iter_done, hipEventDisableTiming))) break;
             if ((e = hipEventCreateWithFlags(&ln.ev_out_done, hipEventDisableTiming))) break;
@@ -272,7 +270,7 @@ void fl_ctx_destroy(fl_ctx *c)
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
-        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_de_ctr); hipFree(ln.d_log); hipFree(ln.d_dir);
+        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_log); hipFree(ln.d_dir);
         if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
         if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
@@ -697,11 +695,10 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         if (!c->env_de_split) {
             // One kernel per direction (de.hip): N ping-pongs between the back and front buffers
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-            HIPCHK(hipMemsetAsync(L(c).d_de_ctr, 0, 64 * sizeof(uint32_t), st));
             launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
             L(c).pend_yuv = false;
             for (int pat = 0; pat < 8; ++pat) {
-                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4], L(c).d_de_ctr);
+                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb);
             }
             L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;

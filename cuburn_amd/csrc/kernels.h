@@ -86,7 +86,7 @@ void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 
 // de.hip
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, uint32_t *tile_ctr /* [8 directions][8 XCDs], zeroed */);
+                   float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv);
 
 // output.hip
