@@ -90,6 +90,7 @@ struct fl_genome {
     std::vector<int32_t> prog;
     IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
     hipFunction_t rtc_fn[2][2][4] = {};     // [nw == 8][count][acc] once compiled
+    unsigned rtc_epoch = 0;                 // module-cache epoch the handles above belong to
     bool rtc_failed = false;                // compile / load failed once: stay on the interpreter kernel
     uint32_t nops = 0, nrows = 0, pstride = 0;
     int32_t *d_prog = nullptr, *d_ops = nullptr;
@@ -550,6 +551,8 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     // interpreter kernel if hipRTC is unavailable, switched off, or the compile failed
     hipFunction_t fn = nullptr;
     if (c->use_rtc && !g->rtc_failed && kacc != 2) {
+        const unsigned ep = rtc_epoch();
+        if (g->rtc_epoch != ep) { memset(g->rtc_fn, 0, sizeof g->rtc_fn); g->rtc_epoch = ep; }     // the module cache was flushed
         hipFunction_t &slot = g->rtc_fn[c->nw == 8][count ? 1 : 0][kacc];
         if (!slot) {
             std::string err;

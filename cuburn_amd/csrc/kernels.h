@@ -39,6 +39,7 @@ struct IterSpec {
     std::vector<std::vector<int>> vids;          // flam3 variation numbers in application order
 };
 bool rtc_available();
+unsigned rtc_epoch();      // changes when cached modules were unloaded: function handles obtained before are void
 int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err);
 int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err);
 // launch_iter through a run-time compiled kernel (same arguments)

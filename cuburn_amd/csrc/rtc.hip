@@ -59,6 +59,7 @@ const Api &api() { static Api a = load_api(); return a; }
 struct Entry { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; };
 std::mutex g_mu;
 std::map<std::string, Entry> g_cache;           // key: device + generated header
+unsigned g_epoch = 1;                           // bumped whenever modules are unloaded: handles held by callers expire
 const size_t kMaxModules = 64;                  // (the reference keeps 20, render.py:229)
 
 std::string spec_header(const IterSpec &s, int nw, bool count, int acc)
@@ -122,6 +123,8 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
     return 0;
 }
 
+unsigned rtc_epoch() { std::lock_guard<std::mutex> lock(g_mu); return g_epoch; }
+
 int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err)
 {
     const std::string key = std::to_string(device) + "|" + spec_header(spec, nw, count, acc);
@@ -139,6 +142,7 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int ac
         (void)hipDeviceSynchronize();
         for (auto &kv : g_cache) (void)hipModuleUnload(kv.second.mod);
         g_cache.clear();
+        ++g_epoch;
     }
     g_cache[key] = e;
     *fn = e.fn;

@@ -227,6 +227,29 @@ def test_duration_event_outlives_a_context_switch():
         render.DurationEvent(m.fb, 0).synchronize()           # no context at all: a clean error, no crash
 
 
+def test_per_genome_kernel_cache_turnover(mgr):
+    """The process keeps at most 64 compiled per-genome kernels (the reference keeps 20 modules,
+    render.py:229-245).  70 different structures force the cache to be emptied; a Renderer made
+    before that keeps working (its kernel is compiled again, not called through a stale handle)."""
+    gnm0, prof = nxf_flame(3, 128, 72)
+    prof = dict(prof, spp=40.0)
+    gp0 = profile.wrap(prof, gnm0)
+    first = render.Renderer(gnm0, gp0)
+    evt, out = mgr.queue_frame(first, gnm0, gp0, 0.5); evt.synchronize()
+    before = np.array(out).astype(np.float64)
+    for n in range(1, 71):
+        gnm, _ = nxf_flame(1 + n % 60, 128, 72)
+        if n >= 60:                                         # more structures: a post affine on xform 0, other variations
+            gnm['xforms']['0']['post_affine'] = configs._affine(3.0 * n, 0.9, 0.0, 0.0)
+            gnm['xforms']['0']['variations'] = {'linear': {'weight': 0.7}, 'bent': {'weight': 0.3}} if n % 2 else {'sinusoidal': {'weight': 1.0}}
+        gp = profile.wrap(prof, gnm)
+        evt, out = mgr.queue_frame(render.Renderer(gnm, gp), gnm, gp, 0.5); evt.synchronize()
+        assert np.array(out)[..., 3].max() > 0, n
+    evt, out = mgr.queue_frame(first, gnm0, gp0, 0.5); evt.synchronize()
+    after = np.array(out).astype(np.float64)
+    assert after[..., 3].max() > 0 and np.abs(after - before).mean() < 8.0
+
+
 def test_default_filter_chain_and_size_changes(mgr):
     """The reference's default chain is bilateral -> logscale -> smearclip (specs.py:107); render it,
     then a different size, then the first size again: buffers are re-sized, walkers / RNG persist, and
