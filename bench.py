@@ -237,8 +237,10 @@ def main():
     # the rocprofv3 runs of profiles/, which use FLAME_LANES=1 too).
     ksteps = max(4, min(args.steps, 16))
     os.environ['FLAME_LANES'] = '1'
+    os.environ['FLAME_NO_INTRA_OVERLAP'] = '1'          # multi-launch frames: drains in series with the iterate kernels
     kmgr = render.RenderManager(device=local, nslots=nslots, host_seed=1042 + rank)
     del os.environ['FLAME_LANES']
+    del os.environ['FLAME_NO_INTRA_OVERLAP']
     kmgr.accum_mode, kmgr.fuse = mgr.accum_mode, mgr.fuse
     krdr = render.Renderer(gnm, gprof)
 

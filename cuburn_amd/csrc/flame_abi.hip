@@ -10,6 +10,7 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "kernels.h"
 #include "flame_device.h"
 
@@ -41,8 +42,13 @@ struct Lane {
     uint32_t *d_hot = nullptr;
     void *d_outpix = nullptr;         // w*h*8 bytes
     size_t outpix_bytes = 0;
-    uint32_t *d_log = nullptr, *d_dir = nullptr;      // binned accumulate: sample log + directory
-    size_t log_words = 0, dir_words = 0;
+    // binned accumulate: sample log + directory.  Two sets: in a frame of several launches the tile
+    // accumulate + flush of launch k run on `aux` while launch k+1 iterates on `stream` into the other set
+    // (the role of the reference's alternating streams inside a frame, cuburn/render.py:340-369)
+    uint32_t *d_log[2] = {nullptr, nullptr}, *d_dir[2] = {nullptr, nullptr};
+    size_t log_words[2] = {0, 0}, dir_words[2] = {0, 0};
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_it[2] = {nullptr, nullptr}, ev_ac[2] = {nullptr, nullptr};   // iterate k queued / drains of launch k done
     float *d_params = nullptr;        // [nslots * pstride] one block per temporal sample = per walker slot (grow-only)
     size_t params_floats = 0;
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
@@ -79,7 +85,7 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    bool env_bin_wide = false, env_de_reference = false, env_de_split = false;
+    bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
 };
 #define L(c) ((c)->lanes[(c)->cur])
@@ -140,6 +146,13 @@ static EvPair *ev_pair(fl_ctx *c, std::vector<EvPair> &list)
     return &c->pool[c->pool_used - 1];
 }
 static void ev_end(fl_ctx *c, EvPair *p) { if (p) hipEventRecord(p->b, L(c).stream); }
+static EvPair *ev_begin_on(fl_ctx *c, std::vector<EvPair> &list, hipStream_t st)
+{
+    EvPair *p = ev_pair(c, list);
+    if (p) hipEventRecord(p->a, st);
+    return p;
+}
+static void ev_end_on(EvPair *p, hipStream_t st) { if (p) hipEventRecord(p->b, st); }
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -222,6 +235,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
+    c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
@@ -241,6 +255,12 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
             if ((e = hipEventCreateWithFlags(&ln.ev_interp_done, hipEventDisableTiming))) break;
             if ((e = hipEventCreateWithFlags(&ln.ev_iter_done, hipEventDisableTiming))) break;
             if ((e = hipEventCreateWithFlags(&ln.ev_out_done, hipEventDisableTiming))) break;
+            if ((e = hipStreamCreateWithFlags(&ln.aux, hipStreamNonBlocking))) break;
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                if ((e = hipEventCreateWithFlags(&ln.ev_it[k], hipEventDisableTiming))) break;
+                e = hipEventCreateWithFlags(&ln.ev_ac[k], hipEventDisableTiming);
+            }
+            if (e) break;
         }
         if (e) break;
         if ((e = hipMemcpy(c->d_rng, seeds, sizeof(fl_mwc) * (size_t)c->nwalkers, hipMemcpyHostToDevice))) break;
@@ -260,18 +280,30 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     return FL_OK;
 }
 
-static void sync_all(fl_ctx *c) { for (int i = 0; i < c->nlanes; ++i) hipStreamSynchronize(c->lanes[i].stream); }
+static void sync_all(fl_ctx *c)
+{
+    for (int i = 0; i < c->nlanes; ++i) { hipStreamSynchronize(c->lanes[i].stream); if (c->lanes[i].aux) hipStreamSynchronize(c->lanes[i].aux); }
+}
 
 void fl_ctx_destroy(fl_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    for (int i = 0; i < 2; ++i) if (c->lanes[i].stream) hipStreamSynchronize(c->lanes[i].stream);
+    for (int i = 0; i < 2; ++i) {
+        if (c->lanes[i].stream) hipStreamSynchronize(c->lanes[i].stream);
+        if (c->lanes[i].aux) hipStreamSynchronize(c->lanes[i].aux);
+    }
     for (int i = 0; i < 2; ++i) {
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
-        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_log); hipFree(ln.d_dir);
+        hipFree(ln.d_params); hipFree(ln.d_palette);
+        for (int k = 0; k < 2; ++k) {
+            hipFree(ln.d_log[k]); hipFree(ln.d_dir[k]);
+            if (ln.ev_it[k]) hipEventDestroy(ln.ev_it[k]);
+            if (ln.ev_ac[k]) hipEventDestroy(ln.ev_ac[k]);
+        }
+        if (ln.aux) hipStreamDestroy(ln.aux);
         if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
         if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
@@ -506,7 +538,7 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
 // Maximum write-enabled rounds of one binned launch (bounds the sample log: nslots*NT*4 B per round)
 #define FL_BIN_MAX_ROUNDS 1024u
 
-static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint32_t *tiles_x, uint32_t *nbins,
+static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, int buf, uint32_t *tiles_x, uint32_t *nbins,
                          uint32_t *nbatch_total, bool *wide)
 {
     const uint32_t nt = (uint32_t)c->nw * 64;
@@ -521,28 +553,33 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, uint
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
     size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
-    if (lw > L(c).log_words) {
-        HIPCHK(hipStreamSynchronize(L(c).stream));
-        hipFree(L(c).d_log); L(c).d_log = nullptr; L(c).log_words = 0;
-        HIPCHK(hipMalloc(&L(c).d_log, lw * 4));
-        L(c).log_words = lw;
+    if (lw > L(c).log_words[buf]) {
+        HIPCHK(hipStreamSynchronize(L(c).stream)); HIPCHK(hipStreamSynchronize(L(c).aux));
+        hipFree(L(c).d_log[buf]); L(c).d_log[buf] = nullptr; L(c).log_words[buf] = 0;
+        HIPCHK(hipMalloc(&L(c).d_log[buf], lw * 4));
+        L(c).log_words[buf] = lw;
     }
-    if (dw > L(c).dir_words) {
-        HIPCHK(hipStreamSynchronize(L(c).stream));
-        hipFree(L(c).d_dir); L(c).d_dir = nullptr; L(c).dir_words = 0;
-        HIPCHK(hipMalloc(&L(c).d_dir, dw * 4));
-        L(c).dir_words = dw;
+    if (dw > L(c).dir_words[buf]) {
+        HIPCHK(hipStreamSynchronize(L(c).stream)); HIPCHK(hipStreamSynchronize(L(c).aux));
+        hipFree(L(c).d_dir[buf]); L(c).d_dir[buf] = nullptr; L(c).dir_words[buf] = 0;
+        HIPCHK(hipMalloc(&L(c).d_dir[buf], dw * 4));
+        L(c).dir_words[buf] = dw;
     }
     return FL_OK;
 }
 
-static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count, int acc = 0)
+// One iterate launch and (binned mode) its tile accumulate.  `buf` selects the log / directory set;
+// `drain` is the stream the accumulate runs on: the lane's own stream, or its aux stream when the
+// launches of a frame are pipelined (then the accumulate waits for this iterate through ev_it[buf]).
+static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nrounds, uint32_t fuse, bool count, int acc = 0,
+                          int buf = 0, hipStream_t drain = nullptr)
 {
+    if (!drain) drain = L(c).stream;
     uint32_t tiles_x = 0, nbins = 0, nbatch_total = 0;
     bool wide = false;
     if (acc == FL_ACCUM_BINNED) {
         if (nrounds <= fuse) return fail(FL_E_INVAL, "binned launch needs write-enabled rounds", __FILE__, __LINE__);
-        int rc = ensure_binned(c, d, nrounds - fuse, &tiles_x, &nbins, &nbatch_total, &wide);
+        int rc = ensure_binned(c, d, nrounds - fuse, buf, &tiles_x, &nbins, &nbatch_total, &wide);
         if (rc) return rc;
     }
     EvPair *e = ev_pair(c, c->iter_ev);
@@ -567,34 +604,39 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     if (fn)
         launch_iter_fn(L(c).stream, fn, c->nw, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                        L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
-                       tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir,
+                       tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
                        e ? e->a : nullptr, e ? e->b : nullptr);
     else
     launch_iter(L(c).stream, c->nw, count, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
-                tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log, L(c).d_dir,
+                tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
                 e ? e->a : nullptr, e ? e->b : nullptr);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
-        EvPair *e2 = ev_begin(c, c->accum_ev);
+        if (drain != L(c).stream) {
+            HIPCHK(hipEventRecord(L(c).ev_it[buf], L(c).stream));
+            HIPCHK(hipStreamWaitEvent(drain, L(c).ev_it[buf], 0));
+        }
+        EvPair *e2 = ev_begin_on(c, c->accum_ev, drain);
         // workgroups per tile: enough of them to fill the chip several times over (~8192 in all),
         // no more — every workgroup zeroes and drains a whole LDS tile whatever its share of records
         uint32_t parts = c->bin_parts ? c->bin_parts : 8192u / nbins;
         parts = parts < 1u ? 1u : parts > 16u ? 16u : parts;
-        launch_accum_tiles(L(c).stream, L(c).d_log, L(c).d_dir, L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
+        launch_accum_tiles(drain, L(c).d_log[buf], L(c).d_dir[buf], L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
                            parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
-        ev_end(c, e2);
+        ev_end_on(e2, drain);
         HIPCHK(hipGetLastError());
     }
     return FL_OK;
 }
 
-static int do_flush(fl_ctx *c, const fl_dim &d, bool use_hot = true)
+static int do_flush(fl_ctx *c, const fl_dim &d, bool use_hot = true, hipStream_t st = nullptr)
 {
-    EvPair *e = ev_begin(c, c->flush_ev);
-    launch_flush(L(c).stream, L(c).d_atom, L(c).d_front, L(c).d_hot, d.ah * d.astride, use_hot);
-    ev_end(c, e);
+    if (!st) st = L(c).stream;
+    EvPair *e = ev_begin_on(c, c->flush_ev, st);
+    launch_flush(st, L(c).d_atom, L(c).d_front, L(c).d_hot, d.ah * d.astride, use_hot);
+    ev_end_on(e, st);
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -618,23 +660,40 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     if (rounds == 0) rounds = 1;
     if (nsamples_run) *nsamples_run = (uint64_t)(rounds * per_round);
     // cuburn/render.py:338-369: launch batches grow 4, 6, 9, 13, ... (x 256 rounds), each
-    // followed by a flush; the first batch also carries the fuse rounds.
+    // followed by a flush; the first batch also carries the fuse rounds.  The reference alternates
+    // two streams so that flush k overlaps iter k+1 (render.py:358-369).  Here, when a binned frame
+    // needs several launches, the iterate kernels stay on the lane's stream and the tile accumulate
+    // + flush of each launch go to the lane's aux stream, with two log / directory sets: launch k+1
+    // iterates while launch k drains.  (Both kernels want the whole chip, so this buys little —
+    // DESIGN.md §4.1 — but it costs nothing and hides the drains' launch gaps.)
+    const uint64_t cap = accum_mode == FL_ACCUM_BINNED ? FL_BIN_MAX_ROUNDS : ~0ull;
+    uint32_t nlaunch = 0;
+    for (uint64_t r = rounds, b = 4; r; b += b / 2) { uint64_t n = std::min(std::min(r, b * 256), cap); r -= n; ++nlaunch; }
+    const bool pipelined = accum_mode == FL_ACCUM_BINNED && nlaunch > 1 && !c->env_no_intra;
+    hipStream_t drain = pipelined ? L(c).aux : L(c).stream;
     uint64_t batch = 4;
-    bool first = true;
+    uint32_t k = 0;
     while (rounds) {
-        uint64_t n = rounds < batch * 256 ? rounds : batch * 256;
-        if (accum_mode == FL_ACCUM_BINNED && n > FL_BIN_MAX_ROUNDS) n = FL_BIN_MAX_ROUNDS;
-        uint32_t f = first ? fuse : 0;
-        if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false, accum_mode))) return rc;
-        if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED))) return rc;
+        const uint64_t n = std::min(std::min(rounds, batch * 256), cap);
+        const uint32_t f = k == 0 ? fuse : 0;
+        const int buf = pipelined ? (int)(k & 1u) : 0;
+        // the drains of launch k-2 read this log / directory set: they must be done before it is rewritten
+        if (pipelined && k >= 2) HIPCHK(hipStreamWaitEvent(L(c).stream, L(c).ev_ac[buf], 0));
+        if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false, accum_mode, buf, drain))) return rc;
+        if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED, drain))) return rc;
+        if (pipelined) HIPCHK(hipEventRecord(L(c).ev_ac[buf], drain));
         rounds -= n;
         batch += batch / 2;
-        first = false;
+        ++k;
     }
     // the walkers are free once the last iterate kernel has run (the drain kernels that follow
-    // touch only this lane's buffers); record after everything queued so far on this stream
+    // touch only this lane's buffers)
     HIPCHK(hipEventRecord(L(c).ev_iter_done, L(c).stream));
     L(c).iter_rec = true;
+    if (pipelined) {                    // whatever comes next on this lane's stream sees the finished accumulator
+        HIPCHK(hipStreamWaitEvent(L(c).stream, L(c).ev_ac[(k - 1) & 1u], 0));
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(L(c).stream, L(c).ev_ac[k & 1u], 0));
+    }
     return FL_OK;
 }
 

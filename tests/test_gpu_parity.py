@@ -298,6 +298,33 @@ def test_per_genome_kernel_equals_interpreter(built, which, monkeypatch, capfd):
             assert np.array_equal(a['front'].view(np.uint32), b['front'].view(np.uint32)), (which, mode)
 
 
+def test_pipelined_launches_equal_serial_launches(built, monkeypatch):
+    """A frame of several launches runs the tile accumulate + flush of launch k on the lane's aux
+    stream while launch k+1 iterates (two log / directory sets; the reference alternates two streams
+    the same way, render.py:340-369).  FLAME_NO_INTRA_OVERLAP=1 keeps everything on one stream.
+    Same kernels on the same data in the same order: the density channel must be identical, colour
+    sums equal up to the order of float adds of drained cells."""
+    gnm, prof = small(configs.cfg3, 640, 360)
+    lib = _lib.load()
+    outs = {}
+    for serial in ('0', '1'):
+        monkeypatch.setenv('FLAME_NO_INTRA_OVERLAP', serial)
+        m = render.RenderManager(device=0, host_seed=42)
+        rdr, gprof, dim, g, ts, td = setup_frame(m, gnm, prof, 0.4)
+        run = C.c_uint64()
+        nsamp = float(5 * 1024 * m.fb.nslots * m.fb.nthreads)          # 5120 rounds: launches of 1024 rounds
+        _lib.check(lib.fl_iterate(m.fb.ctx, g, dim.w, dim.h, nsamp, 64, 1, C.byref(run)))
+        outs[serial] = (run.value, m.fb.read('front', (dim.ah * dim.astride, 4), np.float32),
+                        m.fb.read('seeds', (m.fb.nwalkers, 3), np.uint32))
+        t = m.timings()
+        assert t['launches'] == 5
+        m.fb.free()
+    (na, fa, ra), (nb, fb, rb) = outs['0'], outs['1']
+    assert na == nb and np.array_equal(ra, rb)
+    assert np.array_equal(fa[:, 3], fb[:, 3]) and fa[:, 3].sum() > 0.5 * na
+    np.testing.assert_allclose(fa[:, :3], fb[:, :3], rtol=1e-5, atol=1e-3)
+
+
 def hot_flame():
     """The transcendental-free flame plus a strongly contracting xform: a ~100-pixel region that
     takes 3 % of all samples."""
