@@ -153,3 +153,62 @@ def test_random_genome_parity(mgr, mgr_prod, seed):
         bg, br = blocks(front), blocks(refh)
         l1 = np.abs(bg / bg.sum() - br / br.sum()).sum()
         assert l1 < 0.05, l1
+
+
+def _variation_genome(names):
+    """One xform per variation (plus a little linear so that points keep moving), default parameters."""
+    xforms = {}
+    for i, n in enumerate(names):
+        var = {n: dict([(k, dv if dv else 0.6) for k, (dv, _) in V.var_params[n].items()], weight=0.6)}
+        if n != 'linear':
+            var['linear'] = {'weight': 0.4}
+        xforms['%02d' % i] = {'weight': 1.0, 'color': i / max(len(names) - 1, 1), 'color_speed': 0.5,
+                              'pre_affine': configs._affine(17.0 * i, 0.7, 0.3 * np.cos(i), 0.3 * np.sin(i)),
+                              'variations': var}
+    gnm = {'type': 'animation', 'name': 'vars', 'camera': {'center': {'x': 0.0, 'y': 0.0}, 'rotation': 0.0, 'scale': 0.25},
+           'time': {'duration': 1, 'frame_width': 0.0}, 'palette': [[0.0] + configs.palette_encode(configs.grey_ramp())],
+           'xforms': xforms}
+    prof = {'width': 384, 'height': 216, 'spp': 100.0, 'fps': 1, 'duration': 1, 'frame_width': 0.0,
+            'output': {'type': 'raw'}, 'filter_order': ['bilateral', 'logscale', 'colorclip']}
+    return gnm, prof
+
+
+ALL_VARS = sorted(V.var_ids, key=lambda n: V.var_ids[n])
+
+
+@pytest.mark.parametrize('chunk', list(range(0, len(ALL_VARS), 8)))
+def test_every_variation_per_genome_kernel_equals_interpreter(chunk, monkeypatch):
+    """All 95 variations, eight per genome: the kernel compiled for the genome's structure (hipRTC)
+    and the precompiled interpreter kernel (FLAME_RTC=0) leave identical RNG states, walker points,
+    sample counters and per-cell densities — the specialisation inlines every variation body with a constant
+    id where the interpreter calls one out-of-line function, and must not change a single bit."""
+    lib = _lib.load()
+    names = ALL_VARS[chunk:chunk + 8]
+    gnm, prof = _variation_genome(names)
+    gprof = profile.wrap(prof, gnm)
+    out = {}
+    for rtc in ('0', '1'):
+        monkeypatch.setenv('FLAME_RTC', rtc)
+        m = render.RenderManager(device=0, nslots=NSLOTS, host_seed=5)
+        rdr = render.Renderer(gnm, gprof)
+        g = rdr._handle(m.fb)
+        m._copy(rdr, gnm)
+        dim = m.fb.calc_dim(gprof.width, gprof.height)
+        _lib.check(lib.fl_interp(m.fb.ctx, g, dim.w, dim.h, 0.5, 0.0))
+        _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 1))
+        _lib.check(lib.fl_debug_iter_launch(m.fb.ctx, g, dim.w, dim.h, 0, 20, 4, 1))
+        ctr = np.zeros(4, np.uint64)
+        _lib.check(lib.fl_debug_counters(m.fb.ctx, ctr.ctypes.data))
+        _lib.check(lib.fl_debug_flush(m.fb.ctx, dim.w, dim.h))
+        out[rtc] = (ctr, m.fb.read('seeds', (m.fb.nwalkers, 3), np.uint32),
+                    m.fb.read('points', (NSLOTS * 256, 4), np.float32),
+                    m.fb.read('front', (dim.ah * dim.astride, 4), np.float32))
+        m.fb.free()
+    (ca, ra, pa, fa), (cb, rb, pb, fb) = out['0'], out['1']
+    assert np.array_equal(ca, cb), (names, ca, cb)
+    assert np.array_equal(ra, rb), names
+    both_nan = np.isnan(pa) & np.isnan(pb)
+    assert np.array_equal(pa.view(np.uint32)[~both_nan], pb.view(np.uint32)[~both_nan]), names
+    # densities are integers (exact); colour sums are float atomics whose order varies run to run
+    assert np.array_equal(fa[:, 3], fb[:, 3]), names
+    assert np.allclose(fa[:, :3], fb[:, :3], rtol=1e-5, atol=1e-5), names
