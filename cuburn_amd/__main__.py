@@ -23,54 +23,70 @@ def list_devices():
                                                             p.multi_processor_count, p.total_memory))
 
 
+def _deliver(encoder, frame, basename):
+    """Hand one host frame (None: end of stream) to the output module and write whatever segments it
+    has finished as <basename><suffix>; encoder logs go to stderr."""
+    media, logs = encoder.encode(frame)
+    for suffix in media:
+        seg = media[suffix]
+        with open(basename + suffix, 'wb') as fp:
+            fp.write(seg.read())
+        close = getattr(seg, 'close', None)
+        if close:
+            close()
+    for title, text in logs:
+        print('\n=== %s ===\n%s' % (title, text), file=sys.stderr)
+
+
+def _preview(path, frame):
+    """--raw: the newest frame, replaced atomically so that a viewer never sees half a file."""
+    try:
+        frame.tofile(path + '.tmp')
+        os.rename(path + '.tmp', path)
+    except Exception:
+        print('Failed to write %s: %s' % (path, traceback.format_exc()), file=sys.stderr)
+
+
+def _one_ahead(queue, times):
+    """Yield (index, finished frame) with the next frame already queued behind it (main.py:64-70)."""
+    inflight = None
+    for k, t in enumerate(times):
+        nxt = queue(t)
+        if inflight is not None:
+            yield k, inflight
+        inflight = nxt
+    if inflight is not None:
+        yield len(times), inflight
+
+
 def render(args, prof):
     gnm, basename = store.connect(args.genomedb).animation(args.flame, args.half)
     if getattr(args, 'print'):
         print(convert.to_json(gnm))
         return
     gprof = profile.wrap(prof, gnm)
-    frames = profile.enumerate_jobs(gprof, basename, args)
-    if not frames:
+    jobs = profile.enumerate_jobs(gprof, basename, args)
+    if not jobs:
         return
     from . import render as R
     rmgr = R.RenderManager(device=args.device or 0)
     rdr = R.Renderer(gnm, gprof, keep=args.keep)
-    last_ms = 0
+    tag = ('%d: ' % args.device) if args.device is not None and args.device >= 0 else ''
+    took_ms = 0
 
-    for name, times in frames:
-        def save(buf):
-            out, log = rdr.out.encode(buf)
-            for suffix, file_like in out.items():
-                with open(name + suffix, 'wb') as fp:
-                    fp.write(file_like.read())
-                if getattr(file_like, 'close', None):
-                    file_like.close()
-            for key, val in log:
-                print('\n=== %s ===\n%s' % (key, val), file=sys.stderr)
-
-        pending = None
+    for name, times in jobs:
         times = list(times)
-        for idx, t in enumerate(times + [None]):
-            done, pending = pending, (rmgr.queue_frame(rdr, gnm, gprof, t) if t is not None else None)
-            if done is None:
-                continue
-            evt, buf = done
-            if last_ms > 2000:              # long frames: poll instead of blocking the interpreter
-                while not evt.query():
-                    time.sleep(0.2)
+        for idx, (evt, frame) in _one_ahead(lambda t: rmgr.queue_frame(rdr, gnm, gprof, t), times):
+            while took_ms > 2000 and not evt.query():       # long frames: poll, keep the interpreter responsive
+                time.sleep(0.2)
             evt.synchronize()
-            last_ms = evt.time()
-            save(buf)
+            took_ms = evt.time()
+            _deliver(rdr.out, frame, name)
             if args.rawfn:
-                try:
-                    buf.tofile(args.rawfn + '.tmp')
-                    os.rename(args.rawfn + '.tmp', args.rawfn)
-                except Exception:
-                    print('Failed to write %s: %s' % (args.rawfn, traceback.format_exc()), file=sys.stderr)
-            dev = ('%d: ' % args.device) if args.device is not None and args.device >= 0 else ''
-            print('%s%s (%3d/%3d), %dms' % (dev, name, idx, len(times), last_ms), file=sys.stderr)
+                _preview(args.rawfn, frame)
+            print('%s%s (%3d/%3d), %dms' % (tag, name, idx, len(times), took_ms), file=sys.stderr)
             sys.stderr.flush()
-        save(None)
+        _deliver(rdr.out, None, name)                        # flush: video outputs return their segment here
 
 
 def build_parser():

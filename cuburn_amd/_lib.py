@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('FLAME_HIP_LIB', LIB_PATH)
 FILT = dict(yuv=0, bilateral=1, logscale=2, colorclip=3, smearclip=4, haloclip=5, plainclip=6, logencode=7)
 BUF = dict(front=0, back=1, params=2, palette=3, points=4, seeds=5, atom=6, hot=7, side=8)
 ACCUM_ATOMIC, ACCUM_BINNED = 0, 1
+OUT = dict(rgba8=0, rgba16=1, yuv444p=2, yuv444p10=3, yuv420p10=4, yuv444p12=5)     # include/flame_hip.h FL_OUT_*
 
 
 class fl_dim(C.Structure):
@@ -38,6 +39,7 @@ _SIGS = {
                              C.POINTER(C.c_uint64)]),
     'fl_filter': (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
     'fl_output': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64]),
+    'fl_output_bytes': (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
     'fl_frame_begin': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     'fl_frame_ms': (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     'fl_frame_query': (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -842,9 +842,23 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     return FL_OK;
 }
 
+size_t fl_output_bytes(uint32_t w, uint32_t h, int fmt)
+{
+    const size_t n = (size_t)w * h;
+    switch (fmt) {
+    case FL_OUT_RGBA8: return 4 * n;
+    case FL_OUT_RGBA16: return 8 * n;
+    case FL_OUT_YUV444P: return 3 * n;
+    case FL_OUT_YUV444P10: case FL_OUT_YUV444P12: return 6 * n;
+    case FL_OUT_YUV420P10: return 3 * n;                    // (n + 2 * n/4) * 2 bytes
+    default: return 0;
+    }
+}
+
 int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out)
 {
-    REQUIRE(c && (fmt == 0 || fmt == 1), "bad argument");
+    REQUIRE(c && fl_output_bytes(w, h, fmt) != 0, "bad argument");
+    REQUIRE(fmt != FL_OUT_YUV420P10 || (w % 2 == 0 && h % 2 == 0), "4:2:0 needs even width and height");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -857,7 +871,7 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L(c).ev_out_done, L(c).stream));
     L(c).out_rec = true;
-    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, (size_t)w * h * (fmt ? 8 : 4), hipMemcpyDeviceToHost, L(c).stream));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, fl_output_bytes(w, h, fmt), hipMemcpyDeviceToHost, L(c).stream));
     if (c->frame_seq) HIPCHK(hipEventRecord(c->ev_end_[(c->frame_seq - 1) % fl_ctx::kFrames], L(c).stream));
     return FL_OK;
 }

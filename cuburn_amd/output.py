@@ -1,9 +1,9 @@
 """
 Output modules: pixel-format conversion on device, copy to host, encode.
 
-Role of cuburn/output.py:21-136,411-434 for still images: 8-bit RGBA (jpeg / png / raw) and
-16-bit RGBA (tiff / raw16).  Video encoders (x264, VPx, ProRes pipes) are external programs
-and out of scope.
+Role of cuburn/output.py:21-136,411-434: 8-bit RGBA (jpeg / png / raw) and 16-bit RGBA (tiff /
+raw16) stills here; the outputs that pipe frames into a video encoder (x264, vpxenc, ffmpeg) are
+in encoders.py.
 """
 import io
 import struct
@@ -21,12 +21,16 @@ class Output(object):
     def convert(self, fb, gprof, dim, stream=None):
         """Conversion and copy are one call here; kept for interface parity (output.py:29-37)."""
 
+    def shape(self, dim):
+        """Shape of the host frame ``copy`` returns."""
+        return (dim.h, dim.w, 4)
+
     def copy(self, fb, dim, pool=None, stream=None, dev_out=0, host=True):
         """Queue dither+convert and the async D2H; returns the host array (output.py:85-88).
         ``dev_out``: device address that receives the converted frame instead of the context's own
         pixel buffer (e.g. a tensor that RCCL gathers: no host round trip); ``host=False`` skips the
         D2H copy altogether (returns None)."""
-        h_out = fb.host_buffer((dim.h, dim.w, 4), self.dtype) if host else None
+        h_out = fb.host_buffer(self.shape(dim), self.dtype) if host else None
         _lib.check(_lib.load().fl_output(fb.ctx, dim.w, dim.h, self.fmt, h_out.ctypes.data if host else None, int(dev_out)))
         return h_out
 
@@ -183,8 +187,12 @@ def get_output_for_profile(gprof):
     if handler == 'raw16':
         return Raw16Output()
     if handler in _VIDEO:
-        raise ValueError('Output type "%s" pipes frames into an external encoder, which this build does '
-                         'not drive (SURVEY.md 8 f4); use png / jpeg / tiff / raw.' % handler)
+        from . import encoders
+        if handler == 'x264':
+            return encoders.X264Output(**opts)
+        if handler == 'prores':
+            return encoders.ProResOutput(fps=gprof.fps, **opts)
+        return encoders.VPxOutput(codec=handler, fps=gprof.fps, **opts)
     raise ValueError('Invalid output type "%s".' % handler)
 
 

@@ -107,20 +107,20 @@ def enumerate_times(gprof):
 
 
 def enumerate_jobs(gprof, basename, args, resume=None):
-    """``[(output_basepath, center_times)]`` with optional resume filtering (cuburn/profile.py:129-159)."""
+    """
+    ``[(output path without extension, centre times)]`` for every output file of the run
+    (cuburn/profile.py:129-159).  Files are numbered ``<dir>/<name>_00001<suffix>`` — or
+    ``<dir>/<name>/00001<suffix>`` with ``--subdir``, creating the directory — where ``-n`` replaces
+    the genome's own name.  With ``resume`` (argument, or ``--resume`` when the argument is None)
+    outputs whose file already exists under the output module's extension are left out.
+    """
     from . import output
-    if args.name is not None:
-        basename = args.name
-    prefix = os.path.join(args.dir, basename)
-    if args.subdir:
-        if not os.path.isdir(prefix):
-            os.mkdir(prefix)
-        prefix_plus = prefix + '/'
-    else:
-        prefix_plus = prefix + '_'
-    frames = [('%s%05d%s' % (prefix_plus, i, args.suffix), t) for i, t in enumerate_times(gprof)]
-    resume = args.resume if resume is None else resume
-    if resume:
-        out_suffix = output.get_suffix_for_profile(gprof)
-        frames = [(n, t) for (n, t) in frames if not os.path.isfile(n + out_suffix)]
-    return frames
+    stem = os.path.join(args.dir, basename if args.name is None else args.name)
+    if args.subdir and not os.path.isdir(stem):
+        os.mkdir(stem)
+    pattern = stem + ('/' if args.subdir else '_') + '%05d' + args.suffix
+    jobs = [(pattern % number, times) for number, times in enumerate_times(gprof)]
+    if args.resume if resume is None else resume:
+        ext = output.get_suffix_for_profile(gprof)
+        jobs = [job for job in jobs if not os.path.isfile(job[0] + ext)]
+    return jobs

@@ -197,9 +197,18 @@ enum {
 };
 int fl_filter(fl_ctx *ctx, int filter_id, uint32_t w, uint32_t h, const float *params, uint32_t nparams);
 
-/* cuburn/output.py:83-88,120-125 (convert+copy): f32 -> rgba8 / rgba16 with dither
- * (cuburn/code/output.py:7-71), gutter cropped; async D2H into host_out (or device copy
- * when dev_out != 0). fmt: 0 = u8 x4, 1 = u16 x4. */
+/* cuburn/output.py:83-88,120-125,150-158,212-219,323-338 (convert + copy of every Output class):
+ * f32 -> pixel format with dither (cuburn/code/output.py:7-236), gutter cropped; async D2H into
+ * host_out (or device copy when dev_out != 0).  fl_output_bytes gives the frame's size. */
+enum {
+    FL_OUT_RGBA8 = 0,     /* f32_to_rgba_u8    code/output.py:20-44    u8  [h][w][4]                        */
+    FL_OUT_RGBA16 = 1,    /* f32_to_rgba_u16   code/output.py:47-71    u16 [h][w][4]                        */
+    FL_OUT_YUV444P = 2,   /* f32_to_yuv444p    code/output.py:75-102   u8  [3][h][w], JPEG full range       */
+    FL_OUT_YUV444P10 = 3, /* f32_to_yuv444p10  code/output.py:106-134  u16 [3][h][w], peak 1023             */
+    FL_OUT_YUV420P10 = 4, /* f32_to_yuv420p10  code/output.py:138-190  u16 Y[h][w] Cb[h/2][w/2] Cr[h/2][w/2]; w, h even */
+    FL_OUT_YUV444P12 = 5  /* f32_to_yuv444p12  code/output.py:194-221  u16 [3][h][w], Rec.709 studio swing  */
+};
+size_t fl_output_bytes(uint32_t w, uint32_t h, int fmt);   /* 0 for an unknown format */
 int fl_output(fl_ctx *ctx, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out);
 
 /* cuburn/render.py:404,430 timing_event / DurationEvent: fl_frame_begin opens a frame and returns

@@ -315,6 +315,64 @@ static void ref_f32_to_rgba_impl(const ref_dim *d, const float *src, ref_mwc *rn
         }
 }
 
+/* cuburn/code/output.py:73-236: the planar YUV formats the video encoders take.
+ *   fmt 2  f32_to_yuv444p    (:75-102)   u8,  JPEG full-range matrix, three w x h planes
+ *   fmt 3  f32_to_yuv444p10  (:106-134)  u16, same matrix, peak 1023; the Cb plane is stored
+ *          UNdithered (`dst = 1023.0f * cb`, :129) although its dither draw is made (:122)
+ *   fmt 4  f32_to_yuv420p10  (:138-190)  u16, luma per pixel; chroma sample (x, y), x < w/2, y < h/2,
+ *          is the alpha-weighted mean over source pixels (2x..2x+1, 2y..2y+1) (:157-183), planes
+ *          Y[w*h] Cb[w*h/4] Cr[w*h/4]
+ *   fmt 5  f32_to_yuv444p12  (:194-221)  u16, Rec.709 matrix, studio swing (256 + 3504 / 3584), RGB
+ *          clamped to [0, 1] first
+ * RNG assignment of the device model as for the rgba formats: state t serves pixels t, t+nrng, ...;
+ * a pixel draws for Y, Cb, Cr in that order (in 4:2:0 the thread of pixel (x, y) of the top-left
+ * quadrant also produces chroma sample (x, y), after its luma, as in the reference). */
+static inline uint16_t sat_u16(float v) { return v >= 65535.0f ? 65535 : v > 0.0f ? (uint16_t)v : 0; }
+
+static inline float yuv_cb(const float *in) { return -0.168736f * in[0] - 0.331264f * in[1] + 0.5f * in[2]; }
+static inline float yuv_cr(const float *in) { return 0.5f * in[0] - 0.418688f * in[1] - 0.081312f * in[2]; }
+
+static void ref_f32_to_yuv_impl(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst)
+{
+    const size_t npix = (size_t)d->w * d->h;
+    uint8_t *d8 = (uint8_t *)dst;
+    uint16_t *d16 = (uint16_t *)dst;
+    for (uint32_t t = 0; t < nrng; ++t)
+        for (size_t p = t; p < npix; p += nrng) {
+            const uint32_t x = (uint32_t)(p % d->w), y = (uint32_t)(p / d->w);
+            const float *in = &src[4 * ((size_t)d->astride * (y + 12) + x + 12)];
+            ref_mwc *r = &rng[t];
+            if (fmt == 2 || fmt == 3) {
+                const float peak = fmt == 2 ? 255.0f : 1023.0f;
+                const float cb = yuv_cb(in) + 0.5f;
+                const float fy = dclampf(r, peak, 0.299f * in[0] + 0.587f * in[1] + 0.114f * in[2]);
+                const float fb = dclampf(r, peak, cb);
+                const float fr = dclampf(r, peak, yuv_cr(in) + 0.5f);
+                if (fmt == 2) { d8[p] = (uint8_t)fy; d8[npix + p] = (uint8_t)fb; d8[2 * npix + p] = (uint8_t)fr; }
+                else { d16[p] = (uint16_t)fy; d16[npix + p] = sat_u16(1023.0f * cb); d16[2 * npix + p] = (uint16_t)fr; }
+            } else if (fmt == 4) {
+                d16[p] = (uint16_t)dclampf(r, 1023.0f, 0.299f * in[0] + 0.587f * in[1] + 0.114f * in[2]);
+                if (x < d->w / 2 && y < d->h / 2) {
+                    const float *q = &src[4 * ((size_t)d->astride * (2 * y + 12) + 2 * x + 12)];
+                    float sum = (float)((double)q[3] + 1e-12), cb = q[3] * yuv_cb(q), cr = q[3] * yuv_cr(q);
+                    const float *q1 = q + 4, *q2 = q + 4 * (size_t)d->astride, *q3 = q2 + 4;
+                    sum += q1[3]; cb += q1[3] * yuv_cb(q1); cr += q1[3] * yuv_cr(q1);
+                    sum += q2[3]; cb += q2[3] * yuv_cb(q2); cr += q2[3] * yuv_cr(q2);
+                    sum += q3[3]; cb += q3[3] * yuv_cb(q3); cr += q3[3] * yuv_cr(q3);
+                    const size_t c = (size_t)(d->w / 2) * y + x;
+                    d16[npix + c] = (uint16_t)dclampf(r, 1023.0f, cb / sum + 0.5f);
+                    d16[npix + npix / 4 + c] = (uint16_t)dclampf(r, 1023.0f, cr / sum + 0.5f);
+                }
+            } else {
+                float c[3];
+                for (int k = 0; k < 3; ++k) c[k] = fminf(1.0f, fmaxf(0.0f, in[k]));
+                d16[p] = (uint16_t)(dclampf(r, 3504.0f, 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]) + 256.0f);
+                d16[npix + p] = (uint16_t)(dclampf(r, 3584.0f, -0.11457f * c[0] - 0.38543f * c[1] + 0.5f * c[2] + 0.5f) + 256.0f);
+                d16[2 * npix + p] = (uint16_t)(dclampf(r, 3584.0f, 0.5f * c[0] - 0.45416f * c[1] - 0.04585f * c[2] + 0.5f) + 256.0f);
+            }
+        }
+}
+
 /* ---- public entry points: flush-to-zero wrappers (see fz_enter) ---- */
 void ref_yuv_to_rgb(const ref_dim *d, float *dst, const float *src)
 {
@@ -393,5 +451,6 @@ void ref_logencode(const ref_dim *d, float *dst, const float *src, float degamma
 }
 void ref_f32_to_rgba(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst)
 {
-    ref_f32_to_rgba_impl(d, src, rng, nrng, fmt, dst);      /* integer output: no denormal-sensitive step */
+    if (fmt >= 2) ref_f32_to_yuv_impl(d, src, rng, nrng, fmt, dst);
+    else ref_f32_to_rgba_impl(d, src, rng, nrng, fmt, dst);      /* integer output: no denormal-sensitive step */
 }

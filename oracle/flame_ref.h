@@ -84,7 +84,7 @@ void ref_haloclip_chain(const ref_dim *d, float *front, float *back, float *side
 void ref_plainclip(const ref_dim *d, float *buf, float gam_m_1, float lin, float lingam, float brightness);
 void ref_logencode(const ref_dim *d, float *dst, const float *src, float degamma);
 
-/* cuburn/code/output.py:7-71 */
+/* cuburn/code/output.py:7-236; fmt 0 rgba8, 1 rgba16, 2 yuv444p, 3 yuv444p10, 4 yuv420p10, 5 yuv444p12 */
 void ref_f32_to_rgba(const ref_dim *d, const float *src, ref_mwc *rng, uint32_t nrng, int fmt, void *dst);
 
 #endif

@@ -243,7 +243,12 @@ def logencode(dim, src, degamma):
 
 def f32_to_rgba(dim, src, rng, fmt):
     rng = np.ascontiguousarray(rng, dtype=np.uint32).copy()
-    dst = np.zeros((dim.h, dim.w, 4), dtype=np.uint16 if fmt else np.uint8)
+    if fmt < 2:
+        dst = np.zeros((dim.h, dim.w, 4), dtype=np.uint16 if fmt else np.uint8)
+    elif fmt == 4:
+        dst = np.zeros(dim.h * dim.w * 6 // 4, dtype=np.uint16)
+    else:
+        dst = np.zeros((3, dim.h, dim.w), dtype=np.uint8 if fmt == 2 else np.uint16)
     lib().ref_f32_to_rgba(C.byref(dim), _p(src), _p(rng), len(rng), fmt, _p(dst))
     return dst, rng
 

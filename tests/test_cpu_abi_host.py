@@ -122,6 +122,11 @@ def test_unknown_variation_rejected_on_host():
         GenomePacker({'type': 'animation', 'xforms': {}})
 
 
+def output_dim(w, h):
+    from cuburn_amd.render import Framebuffers
+    return Framebuffers.calc_dim(w, h)
+
+
 def _wrap_output(otype, **kw):
     gnm, prof = configs.cfg1()
     return profile.wrap(dict(prof, output=dict(type=otype, **kw)), gnm)
@@ -137,9 +142,19 @@ def test_output_modules_for_profile_types():
     assert isinstance(o, output.TiffOutput) and o.fmt == 1 and o.dtype == 'u2'
     o = output.get_output_for_profile(_wrap_output('jpeg', quality=90))
     assert isinstance(o, output.PILOutput) and o.fmt == 0 and o.quality == 90
-    for video in ('x264', 'vp8', 'vp9', 'prores'):
-        with pytest.raises(ValueError):
-            output.get_output_for_profile(_wrap_output(video))
+    from cuburn_amd import encoders
+    o = output.get_output_for_profile(_wrap_output('x264', crf=20))
+    assert isinstance(o, encoders.X264Output) and o.fmt == 1 and o.dtype == 'u2' and '20' in o.args
+    o = output.get_output_for_profile(_wrap_output('vp8'))
+    assert isinstance(o, encoders.VPxOutput) and o.fmt == 2 and o.dtype == 'u1' and '--codec=vp8' in o.args
+    o = output.get_output_for_profile(_wrap_output('vp9', pix_fmt='yuv420p10'))
+    assert o.fmt == 4 and o.dtype == 'u2' and o.shape(output_dim(64, 32)) == (64 * 32 * 6 // 4,)
+    o = output.get_output_for_profile(_wrap_output('prores'))
+    assert isinstance(o, encoders.ProResOutput) and o.fmt == 5 and o.shape(output_dim(64, 32)) == (3, 32, 64)
+    assert output.get_suffix_for_profile(_wrap_output('vp9')) == '.webm'
+    assert output.get_suffix_for_profile(_wrap_output('x264', alpha=True)) == '_color.h264'
+    with pytest.raises(ValueError):
+        output.get_output_for_profile(_wrap_output('vp8', pix_fmt='yuv444p10'))      # high bit depth is vp9 only
     with pytest.raises(ValueError):
         output.get_output_for_profile(_wrap_output('bogus'))
 

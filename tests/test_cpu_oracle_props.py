@@ -217,3 +217,69 @@ def test_output_conversion_ranges():
         assert (out == peak).all()
         out, _ = O.f32_to_rgba(d, np.full((n, 4), 0.5, np.float32), rng, fmt)
         assert out.min() >= int(0.5 * peak) and out.max() <= int(0.5 * peak) + 1
+
+
+def _plane_input(d, pixels=(), fill=0.0):
+    buf = np.full((d.ah, d.astride, 4), fill, np.float32)
+    for (y, x), v in pixels:
+        buf[12 + y, 12 + x] = v
+    return buf.reshape(-1, 4)
+
+
+def test_yuv_output_known_answers():
+    """The reference's own pixel-format tests (cuburn/code/tests/test_output.py:23-125) on the oracle."""
+    d = O.calc_dim(640, 360)
+    rng = mwc.make_seeds(4096, 11)
+    # :23-53 clamping below 0 / above 1 (yuv444p): luma pinned, chroma neutral
+    for fill, luma in ((-1.0, 0), (5.0, 255)):
+        out, _ = O.f32_to_rgba(d, _plane_input(d, fill=fill), rng, 2)
+        assert out.shape == (3, 360, 640) and out.dtype == np.uint8
+        assert (out[0] == luma).all() and out[1].min() >= 127 and out[1].max() <= 128 and out[2].min() >= 127 and out[2].max() <= 128
+    # :55-67 yuv444p10 zero pass-through
+    out, _ = O.f32_to_rgba(d, _plane_input(d), rng, 3)
+    assert (out[0] == 0).all() and (out[1] > 510).all() and (out[1] < 513).all() and (out[2] > 510).all() and (out[2] < 513).all()
+    # :69-85 yuv444p10 chroma address preservation
+    green = [0, 1, 0, 1]
+    out, _ = O.f32_to_rgba(d, _plane_input(d, [((0, 0), green), ((1, 1), green)]), rng, 3)
+    assert out[0, 0, 0] > 0 and out[0, 1, 1] > 0 and out[1, 0, 0] < 500 and out[1, 1, 1] < 500
+    assert out[0, 0, 1] == 0 and 510 < out[1, 0, 1] < 513
+    # :87-125 yuv420p10: chroma (0,0) from one green pixel, chroma (1,1) the mean of a green and a red one
+    out, _ = O.f32_to_rgba(d, _plane_input(d, [((0, 0), green), ((2, 2), green), ((3, 3), [1, 0, 0, 1])]), rng, 4)
+    w, h = 640, 360
+    assert out.shape == (w * h * 6 // 4,)
+    luma = out[:w * h].reshape(h, w)
+    cb = out[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    cr = out[w * h + w * h // 4:].reshape(h // 2, w // 2)
+    assert luma[0, 0] > 0 and luma[1, 0] == 0 and luma[0, 1] == 0 and luma[1, 1] == 0 and luma[2, 2] > 0 and luma[3, 3] > 0
+    assert 172 <= cb[0, 0] <= 174 and 511 <= cb[0, 1] <= 512 and 511 <= cb[1, 0] <= 512
+    # green + red, equal alpha: cb = (0.168736 + 0.331264) / 2 ... evaluated by hand
+    want_cb = 1023 * ((-0.331264 - 0.168736) / 2 + 0.5)
+    want_cr = 1023 * ((-0.418688 + 0.5) / 2 + 0.5)
+    assert want_cb <= cb[1, 1] <= want_cb + 1 and want_cr - 1 <= cr[1, 1] <= want_cr + 1
+    # 12-bit studio swing: black = 256 / 2048 / 2048, white = 3760 / 2048 / 2048 (+ dither below one code)
+    out, _ = O.f32_to_rgba(d, _plane_input(d, fill=0.0), rng, 5)
+    assert (out[0] == 256).all() and (np.abs(out[1].astype(int) - 2048) <= 1).all() and (np.abs(out[2].astype(int) - 2048) <= 1).all()
+    out, _ = O.f32_to_rgba(d, _plane_input(d, fill=7.0), rng, 5)
+    assert (out[0] == 3760).all() and (np.abs(out[1].astype(int) - 2048) <= 1).all()
+
+
+def test_yuv_output_rng_use():
+    """Three draws per pixel (Y, Cb, Cr) wherever the value is positive; in 4:2:0 only the top-left
+    quadrant's pixels draw for chroma.  States advance exactly that often."""
+    d = O.calc_dim(16, 8)
+    n = d.ah * d.astride
+    rng = mwc.make_seeds(32, 3)
+    buf = np.full((n, 4), 0.5, np.float32)
+    for fmt, draws in ((2, 3 * 128), (3, 3 * 128), (5, 3 * 128), (4, 128 + 2 * 32)):
+        _, after = O.f32_to_rgba(d, buf, rng, fmt)
+        steps = 0
+        for t in range(32):
+            mul, state, carry = (int(v) for v in rng[t])
+            k = 0
+            while (state, carry) != (int(after[t, 1]), int(after[t, 2])):
+                v = mul * state + carry                  # cuburn/code/mwc.py:56-63
+                state, carry = v & 0xffffffff, v >> 32
+                k += 1
+                assert k <= 64
+            steps += k
+        assert steps == draws, (fmt, steps, draws)

@@ -5,6 +5,7 @@ that must survive a change of image size.  The xform-choice tests use linear-onl
 histograms are bit-exact against the oracle's device model.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -326,3 +327,35 @@ def test_long_run_without_timing_queries(mgr):
     evt, out = mgr.queue_frame(rdr, gnm, gprof, 0.5); evt.synchronize()
     t = mgr.timings()
     assert t['launches'] == 1 and t['iter_ms'] > 0 and t['filter_ms'] > 0
+
+
+def test_cli_renders_stills_and_a_video_shard(tmp_path, monkeypatch, capfd):
+    """python -m cuburn_amd end to end (the reference's main.py loop): PNG stills of two frames, then
+    the same animation as one x264 shard through an `x264` found on PATH (a stand-in that copies its
+    input): the segment holds every frame of the shard in the encoder's input format."""
+    import json, stat, sys
+    from cuburn_amd import __main__ as cli
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
+    (tmp_path / 'A.json').write_text(json.dumps(gold['db']['A']))
+    out = tmp_path / 'out'; out.mkdir()
+    common = ['A', '-d', str(tmp_path), '-o', str(out), '--width', '160', '--height', '90', '--spp', '50',
+              '--duration', '1', '--fps', '4']
+    assert cli.main(common + ['--codec', 'png', '--start', '1', '--end', '3']) == 0
+    stills = sorted(os.listdir(str(out)))
+    assert len(stills) == 2 and all(n.endswith('.png') for n in stills), stills
+    assert open(str(out / stills[0]), 'rb').read(8) == b'\x89PNG\r\n\x1a\n'
+    assert '(  1/  1)' in capfd.readouterr().err
+    # video: one shard of 4 frames
+    bindir = tmp_path / 'bin'; bindir.mkdir()
+    fake = bindir / 'x264'
+    fake.write_text('#!%s\nimport sys\nsys.stderr.write("fake x264\\n")\nsys.stdout.buffer.write(sys.stdin.buffer.read())\n' % sys.executable)
+    os.chmod(str(fake), os.stat(str(fake)).st_mode | stat.S_IXUSR)
+    monkeypatch.setenv('PATH', str(bindir) + os.pathsep + os.environ.get('PATH', ''))
+    assert cli.main(common + ['--codec', 'x264', '--shard', '1', '-n', 'clip']) == 0
+    segs = [n for n in os.listdir(str(out)) if n.endswith('.h264')]
+    assert segs == ['clip_00001.h264']
+    data = np.fromfile(str(out / segs[0]), np.uint16)
+    assert data.size == 4 * 90 * 160 * 3 and data.max() > 50
+    frames = data.reshape(4, 90, 160, 3)
+    assert np.abs(frames[0].astype(np.int64) - frames[3].astype(np.int64)).mean() > 0.05      # the animation moves
+    assert 'fake x264' in capfd.readouterr().err

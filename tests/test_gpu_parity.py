@@ -614,6 +614,93 @@ def test_output_bit_exact(mgr, fmt):
     assert (out[buf.reshape(dim.ah, dim.astride, 4)[12:12 + FH, 12:12 + FW] > 1.0] == peak).all()
 
 
+@pytest.mark.parametrize('fmt', [2, 3, 4, 5])
+def test_output_yuv_bit_exact(mgr, fmt):
+    """Planar YUV for the video encoders (cuburn/code/output.py:75-221): every plane and the dither
+    RNG states afterwards equal the oracle's, bit for bit."""
+    lib = _lib.load()
+    dim = mgr.fb.calc_dim(FW, FH); d = O.calc_dim(FW, FH)
+    assert FW % 2 == 0 and FH % 2 == 0
+    rs = np.random.RandomState(6)
+    buf = rs.uniform(-0.2, 1.3, (dim.ah * dim.astride, 4)).astype(np.float32)
+    buf[rs.uniform(size=len(buf)) < 0.3] = 0.0                 # empty pixels: zero alpha in the 4:2:0 weights
+    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 0))
+    mgr.fb.write('front', buf)
+    seeds = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
+    nwalk = walkers(mgr)[2]
+    ref, rng_after = O.f32_to_rgba(d, buf, seeds[nwalk + 64 * 256:], fmt)
+    assert lib.fl_output_bytes(FW, FH, fmt) == ref.nbytes
+    out = np.zeros_like(ref)
+    _lib.check(lib.fl_output(mgr.fb.ctx, FW, FH, fmt, out.ctypes.data, 0))
+    _lib.check(lib.fl_ctx_sync(mgr.fb.ctx))
+    after = mgr.fb.read('seeds', (mgr.fb.nwalkers, 3), np.uint32)
+    assert np.array_equal(after[nwalk + 64 * 256:], rng_after)
+    assert np.array_equal(out, ref)
+
+
+def test_output_yuv_reference_known_answers(mgr):
+    """cuburn/code/tests/test_output.py:23-125 through the device, at the reference's 640x360."""
+    lib = _lib.load()
+    w, h = 640, 360
+    dim = mgr.fb.set_dim(w, h)
+    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, w, h, 0))        # allocates the buffers for this size
+
+    def run(fmt, pixels=(), fill=0.0):
+        buf = np.full((dim.ah, dim.astride, 4), fill, np.float32)
+        for (y, x), v in pixels:
+            buf[12 + y, 12 + x] = v
+        mgr.fb.write('front', buf.reshape(-1, 4))
+        out = np.zeros(lib.fl_output_bytes(w, h, fmt), np.uint8)
+        _lib.check(lib.fl_output(mgr.fb.ctx, w, h, fmt, out.ctypes.data, 0))
+        _lib.check(lib.fl_ctx_sync(mgr.fb.ctx))
+        return out if fmt == 2 else out.view(np.uint16)
+
+    for fill, luma in ((-1.0, 0), (5.0, 255)):
+        o = run(2, fill=fill).reshape(3, h, w)
+        assert (o[0] == luma).all() and o[1].min() >= 127 and o[1].max() <= 128 and o[2].min() >= 127 and o[2].max() <= 128
+    o = run(3).reshape(3, h, w)
+    assert (o[0] == 0).all() and (o[1] > 510).all() and (o[1] < 513).all() and (o[2] > 510).all() and (o[2] < 513).all()
+    green = [0, 1, 0, 1]
+    o = run(3, [((0, 0), green), ((1, 1), green)]).reshape(3, h, w)
+    assert o[0, 0, 0] > 0 and o[0, 1, 1] > 0 and o[1, 0, 0] < 500 and o[1, 1, 1] < 500
+    o = run(4, [((0, 0), green), ((2, 2), green), ((3, 3), [1, 0, 0, 1])])
+    luma = o[:w * h].reshape(h, w)
+    cb = o[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    assert luma[0, 0] > 0 and luma[1, 0] == 0 and luma[0, 1] == 0 and luma[1, 1] == 0 and luma[2, 2] > 0 and luma[3, 3] > 0
+    assert 172 <= cb[0, 0] <= 174 and 511 <= cb[0, 1] <= 512 and 511 <= cb[1, 0] <= 512
+    # odd sizes cannot be subsampled
+    assert lib.fl_output(mgr.fb.ctx, 641, 360, 4, None, 0) == _lib.FL_E_INVAL
+    assert lib.fl_output(mgr.fb.ctx, 640, 360, 6, None, 0) == _lib.FL_E_INVAL and lib.fl_output_bytes(640, 360, 6) == 0
+    mgr.fb.set_dim(FW, FH)
+
+
+def test_video_outputs_through_queue_frame(mgr, tmp_path):
+    """A profile with a video output renders through queue_frame into the encoder's pixel format and
+    the encoder receives exactly the frames the device produced."""
+    import os, stat, sys
+    from cuburn_amd import encoders
+    fake = tmp_path / 'enc'
+    fake.write_text('#!%s\nimport sys\nsys.stdout.buffer.write(sys.stdin.buffer.read())\n' % sys.executable)
+    os.chmod(str(fake), os.stat(str(fake)).st_mode | stat.S_IXUSR)
+    gnm, prof = small(configs.cfg3, 320, 180, samples=2 ** 22)
+    for out, nbytes in ((encoders.VPxOutput(codec='vp9', pix_fmt='yuv420p10', command=str(fake)), 320 * 180 * 3),
+                        (encoders.VPxOutput(codec='vp8', command=str(fake)), 320 * 180 * 3 // 2),
+                        (encoders.X264Output(command=str(fake)), 320 * 180 * 6)):
+        gprof = profile.wrap(prof, gnm)
+        rdr = render.Renderer(gnm, gprof)
+        rdr.out = out
+        sent = 0
+        for tc in (0.25, 0.5):
+            evt, h_out = mgr.queue_frame(rdr, gnm, gprof, tc)
+            evt.synchronize()
+            assert h_out.shape == out.shape(mgr.fb.calc_dim(320, 180)) and h_out.dtype == np.dtype(out.dtype)
+            assert h_out.max() > 0
+            assert out.encode(h_out) == ({}, [])
+            sent += 1
+        media, logs = out.encode(None)
+        assert len(next(iter(media.values())).read()) == sent * nbytes
+
+
 def test_queue_frame_end_to_end(mgr):
     """The drop-in entry point: Renderer + RenderManager.queue_frame -> (evt, h_out)."""
     gnm, prof = small(configs.cfg3, 320, 180, samples=2 ** 24)
