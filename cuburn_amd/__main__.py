@@ -3,7 +3,9 @@ Command line renderer: ``python -m cuburn_amd ID [-d GENOMEDB] [profile options]
 
 Same arguments and frame loop as the reference's main.py:29-137 (double-buffered: frame k+1
 is queued before frame k is waited for and written), over the HIP path.  ``--list-devices``
-lists the HIP devices; ``--print`` prints the blended animation and exits.
+lists the HIP devices; ``--print`` prints the blended animation and exits.  Started once per GPU
+(``python -m torch.distributed.run --nproc-per-node N -m cuburn_amd ...``) the processes share the
+output files between them — the role of the reference's distribute.py (see jobs.py).
 """
 import argparse
 import os
@@ -11,7 +13,7 @@ import sys
 import time
 import traceback
 
-from . import profile
+from . import jobs, profile
 from .genome import convert, store
 
 
@@ -25,15 +27,9 @@ def list_devices():
 
 def _deliver(encoder, frame, basename):
     """Hand one host frame (None: end of stream) to the output module and write whatever segments it
-    has finished as <basename><suffix>; encoder logs go to stderr."""
+    has finished as <basename><suffix> (complete files only: .tmp + rename); encoder logs go to stderr."""
     media, logs = encoder.encode(frame)
-    for suffix in media:
-        seg = media[suffix]
-        with open(basename + suffix, 'wb') as fp:
-            fp.write(seg.read())
-        close = getattr(seg, 'close', None)
-        if close:
-            close()
+    jobs.write_segments(media, basename)
     for title, text in logs:
         print('\n=== %s ===\n%s' % (title, text), file=sys.stderr)
 
@@ -60,33 +56,44 @@ def _one_ahead(queue, times):
 
 
 def render(args, prof):
+    """Render every output file of the run; under a one-process-per-GPU launcher (WORLD_SIZE > 1) this
+    process takes its share of the files on its own GPU (jobs.py).  Returns the number of files lost."""
     gnm, basename = store.connect(args.genomedb).animation(args.flame, args.half)
     if getattr(args, 'print'):
         print(convert.to_json(gnm))
-        return
+        return 0
     gprof = profile.wrap(prof, gnm)
-    jobs = profile.enumerate_jobs(gprof, basename, args)
-    if not jobs:
-        return
-    from . import render as R
-    rmgr = R.RenderManager(device=args.device or 0)
+    rank, world, local = jobs.world_from_env()
+    # deal first, filter second: the share of a process must not depend on what the others have finished
+    todo = jobs.deal(profile.enumerate_jobs(gprof, basename, args, resume=False), rank, world)
+    unfinished = set(name for name, _ in profile.enumerate_jobs(gprof, basename, args, resume=True if world > 1 else None))
+    todo = [job for job in todo if job[0] in unfinished]
+    if not todo:
+        return 0
+    from . import render as R, output
+    device = args.device if args.device is not None and args.device >= 0 else (local if world > 1 else 0)
+    rmgr = R.RenderManager(device=device)
     rdr = R.Renderer(gnm, gprof, keep=args.keep)
-    tag = ('%d: ' % args.device) if args.device is not None and args.device >= 0 else ''
-    took_ms = 0
+    tag = ('%d: ' % device) if world > 1 or (args.device is not None and args.device >= 0) else ''
+    took = [0]
 
-    for name, times in jobs:
+    def render_job(name, times):
         times = list(times)
+        rdr.out = output.get_output_for_profile(gprof)       # a fresh encoder per file (a failed job leaves none behind)
         for idx, (evt, frame) in _one_ahead(lambda t: rmgr.queue_frame(rdr, gnm, gprof, t), times):
-            while took_ms > 2000 and not evt.query():       # long frames: poll, keep the interpreter responsive
+            while took[0] > 2000 and not evt.query():        # long frames: poll, keep the interpreter responsive
                 time.sleep(0.2)
             evt.synchronize()
-            took_ms = evt.time()
+            took[0] = evt.time()
             _deliver(rdr.out, frame, name)
             if args.rawfn:
                 _preview(args.rawfn, frame)
-            print('%s%s (%3d/%3d), %dms' % (tag, name, idx, len(times), took_ms), file=sys.stderr)
+            print('%s%s (%3d/%3d), %dms' % (tag, name, idx, len(times), took[0]), file=sys.stderr)
             sys.stderr.flush()
         _deliver(rdr.out, None, name)                        # flush: video outputs return their segment here
+
+    done, lost = jobs.run_jobs(todo, render_job)
+    return len(lost)
 
 
 def build_parser():
@@ -113,8 +120,7 @@ def main(argv=None):
     if not args.flame:
         build_parser().error('a flame ID or file is required')
     pname, prof = profile.get_from_args(args)
-    render(args, prof)
-    return 0
+    return 1 if render(args, prof) else 0
 
 
 if __name__ == '__main__':

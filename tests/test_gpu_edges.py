@@ -359,3 +359,27 @@ def test_cli_renders_stills_and_a_video_shard(tmp_path, monkeypatch, capfd):
     frames = data.reshape(4, 90, 160, 3)
     assert np.abs(frames[0].astype(np.int64) - frames[3].astype(np.int64)).mean() > 0.05      # the animation moves
     assert 'fake x264' in capfd.readouterr().err
+
+
+def test_cli_under_a_per_gpu_launcher_shares_the_files(tmp_path, monkeypatch, capfd):
+    """Two processes' worth of environment (RANK 0 / 1 of WORLD_SIZE 2, run one after the other on the
+    one GPU of the test box): each renders its own half of the files, together they are complete,
+    and a second pass finds nothing left to do (resume is forced on, distribute.py:160-161)."""
+    import json
+    from cuburn_amd import __main__ as cli
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'genome_front.json')))
+    (tmp_path / 'A.json').write_text(json.dumps(gold['db']['A']))
+    out = tmp_path / 'out'; out.mkdir()
+    argv = ['A', '-d', str(tmp_path), '-o', str(out), '--width', '160', '--height', '90', '--spp', '20',
+            '--duration', '1', '--fps', '6', '--codec', 'png']
+    monkeypatch.setenv('WORLD_SIZE', '2'); monkeypatch.setenv('LOCAL_RANK', '0')
+    monkeypatch.setenv('RANK', '1')
+    assert cli.main(argv) == 0
+    assert sorted(os.listdir(str(out))) == ['A_00002.png', 'A_00004.png', 'A_00006.png']
+    monkeypatch.setenv('RANK', '0')
+    assert cli.main(argv) == 0
+    assert sorted(os.listdir(str(out))) == ['A_%05d.png' % k for k in range(1, 7)]
+    capfd.readouterr()
+    stamp = {n: os.path.getmtime(str(out / n)) for n in os.listdir(str(out))}
+    assert cli.main(argv) == 0 and capfd.readouterr().err.count('ms') == 0          # nothing rendered again
+    assert stamp == {n: os.path.getmtime(str(out / n)) for n in os.listdir(str(out))}
