@@ -239,8 +239,6 @@ def main():
     os.environ['FLAME_LANES'] = '1'
     os.environ['FLAME_NO_INTRA_OVERLAP'] = '1'          # multi-launch frames: drains in series with the iterate kernels
     kmgr = render.RenderManager(device=local, nslots=nslots, host_seed=1042 + rank)
-    del os.environ['FLAME_LANES']
-    del os.environ['FLAME_NO_INTRA_OVERLAP']
     kmgr.accum_mode, kmgr.fuse = mgr.accum_mode, mgr.fuse
     krdr = render.Renderer(gnm, gprof)
 
@@ -254,6 +252,9 @@ def main():
         return t
     acc = kernel_times(fuse_main)
     acc_ref = kernel_times(256)
+    # the native context reads the switches when it is created, which happens lazily on the first frame
+    del os.environ['FLAME_LANES']
+    del os.environ['FLAME_NO_INTRA_OVERLAP']
     fence()
     if world > 1:
         tt = torch.tensor([elapsed, elapsed_ref], dtype=torch.float64, device=dev)
@@ -296,8 +297,11 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frames' else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
-                                   '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out',
+            'config': {'workload': ('BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
+                                    '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out') if args.config == 'cfg2'
+                       else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
+                            % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame),
+                       'walker_waves': mgr.fb.nw,
                        'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
                        'frames_queued_ahead': args.depth, 'frames_per_gpu': args.steps,

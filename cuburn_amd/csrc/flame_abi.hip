@@ -95,7 +95,7 @@ struct fl_ctx {
 struct fl_genome {
     std::vector<int32_t> prog;
     IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
-    hipFunction_t rtc_fn[2][2][4] = {};     // [nw == 8][count][acc] once compiled
+    hipFunction_t rtc_fn[3][2][4] = {};     // [nw 4 / 8 / 16][count][acc] once compiled
     unsigned rtc_epoch = 0;                 // module-cache epoch the handles above belong to
     bool rtc_failed = false;                // compile / load failed once: stay on the interpreter kernel
     uint32_t nops = 0, nrows = 0, pstride = 0;
@@ -215,14 +215,15 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(FL_E_NODEV, "device is not gfx950 (kernels are built for MI355X only)", __FILE__, __LINE__);
-    // waves per iterate workgroup (4 or 8) follow from the size of the seed table
+    // waves per iterate workgroup (4, 8 or 16) follow from the size of the seed table
     int nw = 0;
     {
         const uint32_t fixed = FL_PAL_H * 256 + FL_NOUT;
         const uint32_t per_wave = nslots * 64u;
-        if (nseeds == fixed + 8u * per_wave) nw = 8;
+        if (nseeds == fixed + 16u * per_wave) nw = 16;
+        else if (nseeds == fixed + 8u * per_wave) nw = 8;
         else if (nseeds == fixed + 4u * per_wave) nw = 4;
-        else return fail(FL_E_INVAL, "nseeds must be nslots*64*NW + 64*256 + 65536 with NW = 4 or 8", __FILE__, __LINE__);
+        else return fail(FL_E_INVAL, "nseeds must be nslots*64*NW + 64*256 + 65536 with NW = 4, 8 or 16", __FILE__, __LINE__);
     }
     fl_ctx *c = new fl_ctx;
     c->device = device;
@@ -590,7 +591,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     if (c->use_rtc && !g->rtc_failed && kacc != 2) {
         const unsigned ep = rtc_epoch();
         if (g->rtc_epoch != ep) { memset(g->rtc_fn, 0, sizeof g->rtc_fn); g->rtc_epoch = ep; }     // the module cache was flushed
-        hipFunction_t &slot = g->rtc_fn[c->nw == 8][count ? 1 : 0][kacc];
+        hipFunction_t &slot = g->rtc_fn[c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
         if (!slot) {
             std::string err;
             if (rtc_iter_kernel(c->device, g->spec, c->nw, count, kacc, &slot, &err)) {
@@ -1080,7 +1081,7 @@ int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n,
 int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
                          char *log, size_t log_bytes)
 {
-    REQUIRE(prog && ops && nprog >= FL_PROG_HDR && (nw == 4 || nw == 8) && acc >= 0 && acc <= 3, "bad argument");
+    REQUIRE(prog && ops && nprog >= FL_PROG_HDR && (nw == 4 || nw == 8 || nw == 16) && acc >= 0 && acc <= 3, "bad argument");
     int rc = check_prog(prog, nprog);
     if (rc) return rc;
     const int xo = prog[5], xs = prog[6], vs = prog[7], nrec = prog[1] + prog[2];

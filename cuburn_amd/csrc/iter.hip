@@ -201,6 +201,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     uint32_t *cnt = stage + bg.rounds * NT + (WIDE ? bg.rounds * NT / 2 : 0);          // [B+1]
     uint32_t *cur = cnt + ((bg.nbins + 1 + 3) & ~3u);                                  // [B+1]
     uint32_t *s_nvalid = cur + ((bg.nbins + 1 + 3) & ~3u);                              // [4]
+    uint32_t *tot = s_nvalid + 4;                                                      // [128] totals of 64-tile chunks
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const uint32_t slot = blockIdx.x, ts = slot, prow = slot * FL_PAL_H / gridDim.x;
@@ -362,18 +363,52 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                     r2[q] = have ? stage[q * NT + tid] : 0u;
                     k2[q] = !have ? 0xffffffffu : WIDE ? (uint32_t)skey[q * NT + tid] : r2[q] >> PAY_BITS;
                 }
-                if (w == 0) {                       // exclusive scan of the tile counts, directory entries
-                    uint32_t running = 0;
-                    for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
-                        const uint32_t b = c0 + l;
-                        const uint32_t v = b <= bg.nbins ? cnt[b] : 0u;
-                        const uint32_t incl = wave_incl_scan(v, l);
-                        const uint32_t excl = incl - v + running;
-                        if (b <= bg.nbins) { cur[b] = excl; cnt[b] = 0; }
-                        if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
-                        if (b == bg.nbins) *s_nvalid = excl;
-                        running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                // Exclusive scan of the tile counts -> scatter cursors and directory entries, by all
+                // waves: chunks of 64 tiles are scanned where they lie (wave w takes chunks w, w + NW,
+                // ...), then every wave adds the prefix of the chunk totals to its own chunks.  (One
+                // wave walking all 2109 tiles of an 8K image kept the other fifteen waiting for 15 %
+                // of the kernel.)
+                const uint32_t nchunk = (bg.nbins + 64u) >> 6;          // tiles 0..nbins, the last one = "no record"
+                if (nchunk <= 8u) {                 // few tiles (1080p: 5 chunks): one wave is quicker than a second barrier
+                    if (w == 0) {
+                        uint32_t running = 0;
+                        for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
+                            const uint32_t b = c0 + l;
+                            const uint32_t v = b <= bg.nbins ? cnt[b] : 0u;
+                            const uint32_t incl = wave_incl_scan(v, l);
+                            const uint32_t excl = incl - v + running;
+                            if (b <= bg.nbins) { cur[b] = excl; cnt[b] = 0; }
+                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+                            if (b == bg.nbins) *s_nvalid = excl;
+                            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        }
                     }
+                } else {
+                for (uint32_t c = w; c < nchunk; c += NW) {
+                    const uint32_t b = c * 64u + l;
+                    const uint32_t v = b <= bg.nbins ? cnt[b] : 0u;
+                    const uint32_t incl = wave_incl_scan(v, l);
+                    if (b <= bg.nbins) cur[b] = incl - v;
+                    if (l == 63u) tot[c] = incl;
+                }
+                __syncthreads();
+                {
+                    const uint32_t t0 = l < nchunk ? tot[l] : 0u, t1 = 64u + l < nchunk ? tot[64u + l] : 0u;   // nchunk <= 128
+                    const uint32_t i0 = wave_incl_scan(t0, l);
+                    const uint32_t i1 = wave_incl_scan(t1, l) + (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+                    for (uint32_t cv = w; cv < nchunk; cv += NW) {
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv);
+                        const uint32_t base = c < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)(i0 - t0), c)
+                                                      : (uint32_t)__builtin_amdgcn_readlane((int)(i1 - t1), c - 64u);
+                        const uint32_t b = c * 64u + l;
+                        if (b <= bg.nbins) {
+                            const uint32_t excl = cur[b] + base, v = cnt[b];
+                            cur[b] = excl; cnt[b] = 0u;
+                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+                            else *s_nvalid = excl;
+                        }
+                    }
+                }
                 }
                 __syncthreads();
                 // scatter, four records per thread in flight (the returning LDS atomic is a
@@ -512,7 +547,7 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
-    if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16;
+    if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + 2 * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16 + 128 * 4;
     else b += FL_PAL_W * 8;
     return b;
 }
@@ -532,17 +567,12 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
         /* the timing events bracket the kernel itself (recorded by the dispatch packet), not the launch call */ \
         hipExtLaunchKernelGGL((k_iter<NW, C, A>), dim3(nslots), dim3(NW * 64), lds, st, ev_start, ev_stop, 0, prog, params, palette, \
         rng, points, hot, atom, out4, counters, astride, aheight, round0, nrounds, fuse, bg, log, dir); } while (0)
-    if (acc == 2) { if (nw == 4) LAUNCH(4, false, 2); else LAUNCH(8, false, 2); }
-    else if (acc == 1) {
-        if (nw == 4) { if (count) LAUNCH(4, true, 1); else LAUNCH(4, false, 1); }
-        else { if (count) LAUNCH(8, true, 1); else LAUNCH(8, false, 1); }
-    }
-    else if (acc == 3) {
-        if (nw == 4) { if (count) LAUNCH(4, true, 3); else LAUNCH(4, false, 3); }
-        else { if (count) LAUNCH(8, true, 3); else LAUNCH(8, false, 3); }
-    }
-    else if (nw == 4) { if (count) LAUNCH(4, true, 0); else LAUNCH(4, false, 0); }
-    else if (nw == 8) { if (count) LAUNCH(8, true, 0); else LAUNCH(8, false, 0); }
+#define LAUNCH_NW(C, A) do { if (nw == 4) LAUNCH(4, C, A); else if (nw == 8) LAUNCH(8, C, A); else LAUNCH(16, C, A); } while (0)
+    if (acc == 2) LAUNCH_NW(false, 2);
+    else if (acc == 1) { if (count) LAUNCH_NW(true, 1); else LAUNCH_NW(false, 1); }
+    else if (acc == 3) { if (count) LAUNCH_NW(true, 3); else LAUNCH_NW(false, 3); }
+    else { if (count) LAUNCH_NW(true, 0); else LAUNCH_NW(false, 0); }
+#undef LAUNCH_NW
 #undef LAUNCH
 }
 
@@ -569,6 +599,7 @@ void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round)
 {
     if (nw == 4) hipLaunchKernelGGL(k_shuffle_tap<4>, dim3(1), dim3(256), 0, st, out, round);
-    else hipLaunchKernelGGL(k_shuffle_tap<8>, dim3(1), dim3(512), 0, st, out, round);
+    else if (nw == 8) hipLaunchKernelGGL(k_shuffle_tap<8>, dim3(1), dim3(512), 0, st, out, round);
+    else hipLaunchKernelGGL(k_shuffle_tap<16>, dim3(1), dim3(1024), 0, st, out, round);
 }
 #endif  // !FL_RTC

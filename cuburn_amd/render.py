@@ -91,14 +91,16 @@ class Framebuffers(object):
     # samples keep the runs per tile long enough for the accumulate (cfg4 4K: 5.61 -> 5.49 ms,
     # cfg5 8K: 97 -> 79 ms per frame; at 1080p the 4-wave geometry is 3 % faster).  Explicit
     # nslots / FLAME_NW pin the geometry.
-    NARROW, WIDE = (4, 1536), (8, 1024)
+    NARROW, WIDE, HUGE = (4, 1536), (8, 1024), (16, 1024)
     WIDE_FROM_TILES = 1024
+    HUGE_FROM_TILES = 2047      # above 4K (where the accumulate switches to 256x64 tiles): 16-wave workgroups,
+                                # batches of 16384 samples (cfg5 8K: 59.1 -> 52.2 ms per frame)
 
     def __init__(self, device=0, nslots=None, host_seed=None, stream=None):
         self.device, self.host_seed, self.stream = device, host_seed, stream
         env_nw = os.environ.get('FLAME_NW')
         self._auto = nslots is None and env_nw is None
-        self._cfg = (8 if env_nw == '8' else 4, nslots if nslots is not None else self.NARROW[1])
+        self._cfg = (int(env_nw) if env_nw in ('8', '16') else 4, nslots if nslots is not None else self.NARROW[1])
         self._ctx = None
         self.generation = 0                 # bumped whenever the native context is re-created
         self.nout = 65536                   # RNG states of the output dither kernel
@@ -146,7 +148,7 @@ class Framebuffers(object):
         dim = self.calc_dim(width, height)
         if self._auto:
             ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
-            want = self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
+            want = self.HUGE if ntiles > self.HUGE_FROM_TILES else self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
             if want != self._cfg:
                 self._drop_ctx()
                 self._cfg = want

@@ -140,7 +140,7 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
 /* cuburn/render.py:253-262 RenderManager.__init__ + :91-104 Framebuffers.__init__:
  * device, streams, walker/RNG state (persistent across frames, render.py:95-104).
  * `seeds` = nseeds x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
- * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536, where NW = 4 or 8 is the number of
+ * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536, where NW = 4, 8 or 16 is the number of
  * waves per iterate workgroup (the table's size selects it): walkers, then the palette kernel's
  * states, then the output dither's.  stream = a hipStream_t to run everything on (single lane), or NULL:
  * the context then owns two streams and alternates consecutive frames between them so that the
@@ -271,7 +271,7 @@ int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
 int fl_debug_apply_xf(fl_ctx *ctx, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng);
 /* Compile (only) the iterate kernel specialised for a genome structure, as fl_iterate does on a genome's
  * first launch — the counterpart of cuburn/render.py:232-236 Renderer.compile.  Needs libhiprtc but no
- * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8, acc = 0 (atomic), 1 / 3 (binned narrow / wide). */
+ * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8 | 16, acc = 0 (atomic), 1 / 3 (binned narrow / wide). */
 int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
                          char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */

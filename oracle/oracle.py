@@ -44,6 +44,7 @@ class ref_geom(C.Structure):
 GEOM_REF = ref_geom(8, 32, 1)       # the reference's 8 warps x 32 lanes (iter.py:106,275-278)
 GEOM_4x64 = ref_geom(4, 64, 0)      # MI355X kernel: 4 waves x 64 lanes
 GEOM_8x64 = ref_geom(8, 64, 0)
+GEOM_16x64 = ref_geom(16, 64, 0)
 
 _lib = None
 

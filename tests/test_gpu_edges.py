@@ -130,7 +130,7 @@ def test_argument_validation(mgr):
     vals = (C.c_float * 2)(1.0, 2.0)
     assert lib.fl_filter(mgr.fb.ctx, _lib.FILT['bilateral'], 256, 144, vals, 2) == _lib.FL_E_INVAL    # too few scalars
     assert lib.fl_filter(mgr.fb.ctx, 999, 256, 144, vals, 2) != 0
-    assert lib.fl_output(mgr.fb.ctx, 256, 144, 5, None, 0) == _lib.FL_E_INVAL                          # bad pixel format
+    assert lib.fl_output(mgr.fb.ctx, 256, 144, 6, None, 0) == _lib.FL_E_INVAL                          # bad pixel format
     ms = C.c_float()
     assert lib.fl_frame_ms(mgr.fb.ctx, 0xfffffff0, C.byref(ms)) == _lib.FL_E_INVAL                     # untracked frame id
     # fl_interp before any upload
@@ -277,9 +277,9 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 
 def test_walker_geometry_follows_image_size():
-    """A manager built without an explicit slot count uses 1536 x 4-wave slots for small images and
-    1024 x 8-wave slots from ~1440p up (the native context is re-created on the switch, genome
-    handles follow)."""
+    """A manager built without an explicit slot count uses 1536 x 4-wave slots for small images,
+    1024 x 8-wave slots from ~1440p up and 1024 x 16-wave slots above 4K (the native context is
+    re-created on the switch, genome handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)
     assert (m.fb.nw, m.fb.nslots) == (4, 1536)
     gnm, prof = configs.cfg2(samples=2 ** 24)
@@ -290,12 +290,15 @@ def test_walker_geometry_follows_image_size():
     evt, a = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()
     assert m.fb.generation == gen0 and np.array(a)[..., 3].max() > 0
     evt, b = m.queue_frame(rdr_b, gnm, big, 0.5); evt.synchronize()
-    assert (m.fb.nw, m.fb.nslots) == (8, 1024) and m.fb.generation == gen0 + 1
+    assert (m.fb.nw, m.fb.nslots) == (16, 1024) and m.fb.generation == gen0 + 1
     b = np.array(b)
     assert b.shape == (4320, 7680, 4) and b[..., 3].max() > 0
-    assert m.last_nsamples % (1024 * 512) == 0
+    assert m.last_nsamples % (1024 * 1024) == 0
+    mid = profile.wrap(dict(prof, width=3840, height=2160, spp=2 ** 25 / (3840.0 * 2160.0)), gnm)
+    evt, c = m.queue_frame(render.Renderer(gnm, mid), gnm, mid, 0.5); evt.synchronize()
+    assert (m.fb.nw, m.fb.nslots) == (8, 1024) and m.fb.generation == gen0 + 2 and np.array(c)[..., 3].max() > 0
     evt, a2 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # same Renderer, new context
-    assert (m.fb.nw, m.fb.nslots) == (4, 1536) and m.fb.generation == gen0 + 2
+    assert (m.fb.nw, m.fb.nslots) == (4, 1536) and m.fb.generation == gen0 + 3
     a, a2 = np.array(a).astype(np.float64), np.array(a2).astype(np.float64)
     assert np.abs(a - a2).mean() < 6.0
     # an explicit slot count pins the geometry

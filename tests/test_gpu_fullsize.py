@@ -160,8 +160,8 @@ def test_cfg5_full_size(built):
     gnm, prof = configs.cfg5()
     m = render.RenderManager(device=0, host_seed=42)
     rdr, gprof, dim, td, nrun, front = iterate_frame(m, gnm, prof, 0.5, 2 ** 32)
-    assert (dim.w, dim.h) == (7680, 4320) and td == 0 and (m.fb.nw, m.fb.nslots) == (8, 1024)
-    assert nrun >= 2 ** 32 and nrun - 2 ** 32 < m.fb.nslots * 512
+    assert (dim.w, dim.h) == (7680, 4320) and td == 0 and (m.fb.nw, m.fb.nslots) == (16, 1024)      # the 16-wave geometry above 4K
+    assert nrun >= 2 ** 32 and nrun - 2 ** 32 < m.fb.nslots * 1024
     check_against_cpu_game(gnm, prof, 0.5, m.fb.nslots, dim, front, nrun, 2 ** 28, 64, 0.02, 2e-3, 1.5 / 255, nthreads=4)   # 537 MB per thread
     vals, dev = filter_chain_on_device(m, rdr, gprof, dim, 0.5)
     x0, y0 = densest_window(dim, front, 1024, 768)

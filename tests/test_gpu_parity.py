@@ -37,7 +37,7 @@ def mgr_prod(built):
 def walkers(mgr):
     """(slots, threads per slot, walker count, oracle geometry) of a manager's current context."""
     ns, nt = mgr.fb.nslots, mgr.fb.nthreads
-    return ns, nt, ns * nt, (O.GEOM_4x64 if nt == 256 else O.GEOM_8x64)
+    return ns, nt, ns * nt, {256: O.GEOM_4x64, 512: O.GEOM_8x64, 1024: O.GEOM_16x64}[nt]
 
 
 def small(cfg, w, h, **kw):
@@ -382,6 +382,43 @@ def test_binned_equals_atomic_equals_oracle(mgr, layout, monkeypatch):
     assert np.array_equal(dev_a[0], dev_b[0]) and np.array_equal(dev_a[1][:, :3], dev_b[1][:, :3])
     if layout == 'wide':
         mgr.fb.free()
+
+
+@pytest.mark.parametrize('nw,nslots,layout', [(8, 1024, 'narrow'), (8, 1024, 'wide'), (16, 1024, 'narrow'), (16, 1024, 'wide')])
+def test_larger_workgroups_bit_exact(nw, nslots, layout, monkeypatch, built):
+    """The 8-wave (from ~1440p) and 16-wave (8K) walker geometries: direct atomics, the binned
+    accumulate and the oracle's device model (same geometry: nw x 64 point swap) agree bit for bit
+    — packed histogram, counters, RNG states and walker points — over two launches with a partial
+    last batch; then a hot flame whose cells drain in LDS and at the tile add."""
+    monkeypatch.setenv('FLAME_NW', str(nw))
+    if layout == 'wide':
+        monkeypatch.setenv('FLAME_BIN_WIDE', '1')
+    m = render.RenderManager(device=0, nslots=nslots, host_seed=43)
+    assert (m.fb.nw, m.fb.nthreads) == (nw, nw * 64) and walkers(m)[3].nw == nw
+    gnm, prof = linear_flame()
+    prof = dict(prof, width=1920, height=1080)
+    gnm['camera']['scale'] = 1.0
+    res_a, ref_a, dev_a, dim, seeds = run_device_model(m, gnm, prof, nrounds=21, fuse=5, launches=2, mode=0)
+    res_b, ref_b, dev_b, dim, _ = run_device_model(m, gnm, prof, nrounds=21, fuse=5, launches=2, mode=1, seeds_in=seeds)
+    for k, (a, b) in enumerate(zip(res_a, res_b)):
+        for r in (a, b):                      # each mode against the oracle run the same way
+            assert int(r['ctr_dev'][3]) == 0 and int(r['ctr_dev'][0]) > 0
+            assert np.array_equal(r['ctr_dev'][:2], r['ctr_ref'][:2])
+            assert np.array_equal(r['atom_dev'], r['atom_ref'])
+            assert np.array_equal(r['front_dev'][:, 3], r['front_ref'][:, 3])
+        if k == 0:                            # no hot flags yet: atomics do not thin, the modes must coincide
+            assert np.array_equal(b['atom_dev'], a['atom_dev']) and np.array_equal(b['front_dev'], a['front_dev'])
+    for dev, ref in ((dev_a, ref_a), (dev_b, ref_b)):
+        assert np.array_equal(dev[0], ref[0])                          # RNG states
+        assert np.array_equal(dev[1][:, :3], ref[1][:, :3])            # walker points
+    gnm, prof = hot_flame()
+    res, ref_state, dev_state, dim, _ = run_device_model(m, gnm, prof, nrounds=40, fuse=16, launches=2, mode=1)
+    for k, r in enumerate(res):
+        assert np.array_equal(r['ctr_dev'][:2], r['ctr_ref'][:2]), (k, r['ctr_dev'], r['ctr_ref'])
+        assert int((r['front_dev'][:, 3] != r['front_ref'][:, 3]).sum()) == 0
+        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=2e-6, atol=1e-4)
+    assert np.array_equal(dev_state[0], ref_state[0])
+    m.fb.free()
 
 
 @pytest.mark.parametrize('layout', ['narrow', 'wide'])
