@@ -28,6 +28,10 @@
 #include <hip/hip_ext.h>
 #endif
 
+#ifndef FL_SCAN_SERIAL_MAX
+#define FL_SCAN_SERIAL_MAX 8u
+#endif
+
 template <int NW>
 __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_t phase) {
     uint32_t sh = l + (phase == 1 ? l / NW : 0u) + (phase == 2 ? l / (NW * NW) : 0u);
@@ -369,7 +373,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 // wave walking all 2109 tiles of an 8K image kept the other fifteen waiting for 15 %
                 // of the kernel.)
                 const uint32_t nchunk = (bg.nbins + 64u) >> 6;          // tiles 0..nbins, the last one = "no record"
-                if (nchunk <= 8u) {                 // few tiles (1080p: 5 chunks): one wave is quicker than a second barrier
+                if (nchunk <= FL_SCAN_SERIAL_MAX) { // few tiles (1080p: 5 chunks): one wave is quicker than a second barrier
                     if (w == 0) {
                         uint32_t running = 0;
                         for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {

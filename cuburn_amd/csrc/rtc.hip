@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 #include "kernels.h"
+#define FL_STR2(x) #x
+#define FL_STR(x) FL_STR2(x)
 #include "rtc_sources.inc"
 
 namespace {
@@ -104,7 +106,11 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
     if (a.create(&prog, rtc_src_iter, "iter.hip", 4, hdr_src, hdr_name) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return -1; }
     // same code generation options as the ahead-of-time build of iter.hip (csrc/Makefile)
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-DFL_RTC=1",
-                          "-mllvm", "-structurizecfg-skip-uniform-regions=true"};
+                          "-mllvm", "-structurizecfg-skip-uniform-regions=true",
+#ifdef FL_SCAN_SERIAL_MAX
+                          "-DFL_SCAN_SERIAL_MAX=" FL_STR(FL_SCAN_SERIAL_MAX),
+#endif
+    };
     const hiprtcResult rc = a.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
