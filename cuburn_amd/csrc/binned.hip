@@ -55,6 +55,9 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
     return v;
 }
 
+#ifndef ACC_ILP_WIDE
+#define ACC_ILP_WIDE 4     /* records per lane in flight, 256x64 tiles (one 16-wave workgroup per CU) */
+#endif
 #ifndef ACC_ILP
 #define ACC_ILP 4
 #endif
@@ -73,6 +76,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
+    constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;
     u64 *tile = reinterpret_cast<u64 *>(smem);                     // [CELLS]
     uint32_t *mk = reinterpret_cast<uint32_t *>(smem + CELLS * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
@@ -109,11 +113,11 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         // replaces a 6-step shuffle binary search + two more shuffles per record (8 trips through
         // the LDS pipe) by one predicated LDS write, one read and one clear per 64 records.
         uint32_t carry = 0;
-        for (uint32_t v0 = 0; v0 < total; v0 += 64 * ACC_ILP) {
-            uint32_t rec[ACC_ILP], row[ACC_ILP];
-            bool live[ACC_ILP];
+        for (uint32_t v0 = 0; v0 < total; v0 += 64 * ILP) {
+            uint32_t rec[ILP], row[ILP];
+            bool live[ILP];
 #pragma unroll
-            for (int k = 0; k < ACC_ILP; ++k) {
+            for (int k = 0; k < ILP; ++k) {
                 const uint32_t lo = v0 + k * 64, v = lo + lane;
                 if (c != 0u && excl - lo < 64u) mk[excl - lo] = (lane << 24) | ((first - excl) & 0xffffffu);
                 wave_sync();                 // lanes exchange data through LDS: without it the compiler
@@ -131,11 +135,11 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 const uint32_t rr = row0 + (uint32_t)(((float)(rem0 + r) + 0.5f) * inv_spr);
                 row[k] = rr >= FL_PAL_H ? rr - FL_PAL_H : rr;                    // the group may wrap past the last slot
             }
-            u64 val[ACC_ILP];
+            u64 val[ILP];
 #pragma unroll
-            for (int k = 0; k < ACC_ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+            for (int k = 0; k < ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
 #pragma unroll
-            for (int k = 0; k < ACC_ILP; ++k) {
+            for (int k = 0; k < ILP; ++k) {
                 if (!live[k]) continue;
                 const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -622,8 +622,10 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         EvPair *e2 = ev_begin_on(c, c->accum_ev, drain);
         // workgroups per tile: enough of them to fill the chip several times over (~8192 in all),
         // no more — every workgroup zeroes and drains a whole LDS tile whatever its share of records
-        uint32_t parts = c->bin_parts ? c->bin_parts : 8192u / nbins;
-        parts = parts < 1u ? 1u : parts > 16u ? 16u : parts;
+        // (256x64 tiles, one workgroup per CU: twice as many — a dense region then spreads over more
+        // workgroups; cfg5 8K: 3 per tile 20.7 ms of accumulate per frame, 8 per tile 16.2, 12: 18.2)
+        uint32_t parts = c->bin_parts ? c->bin_parts : (wide ? 16384u : 8192u) / nbins;
+        parts = parts < 1u ? 1u : parts > (c->bin_parts ? 64u : 16u) ? (c->bin_parts ? 64u : 16u) : parts;
         launch_accum_tiles(drain, L(c).d_log[buf], L(c).d_dir[buf], L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
                            parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
         ev_end_on(e2, drain);
