@@ -157,6 +157,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 
     // add the tile to the global packed accumulator: one row segment of 64 cells per wave
     // instruction (coalesced atomics), draining cells that reach 512 hits
+#ifndef ACC_NO_DRAIN     /* timing experiment only: tools/exp_drain.sh */
     for (uint32_t i = tid; i < CELLS; i += blockDim.x) {
         const u64 v = tile[i];
         const uint32_t px = tx * TW + (i & (TW - 1u)), py = ty * FL_TILE_H + (i >> TWL);
@@ -173,6 +174,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
             }
         }
     }
+#endif
 }
 
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
