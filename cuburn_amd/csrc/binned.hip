@@ -72,13 +72,14 @@ __global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024)
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
-              uint32_t nslots, uint32_t astride, uint32_t aheight)
+              uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
     constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;
     u64 *tile = reinterpret_cast<u64 *>(smem);                     // [CELLS]
     uint32_t *mk = reinterpret_cast<uint32_t *>(smem + CELLS * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
+    u64 *pal = reinterpret_cast<u64 *>(smem + CELLS * 8 + blockDim.x * 4);                     // [rows_cap][256] palette rows in use
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
@@ -87,22 +88,35 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     mk[lane] = 0u;
     __syncthreads();
 
-    // this workgroup's contiguous range of batches
+    // This workgroup's contiguous range of batches.  Batch id = slot * per_slot + batch_in_slot
+    // (iter.hip), so the range covers a narrow range of SLOTS, and with them of palette rows (row of
+    // a batch = its slot * 64 / nslots): the rows in use are staged in LDS — the palette fetch is a
+    // dependent, fully scattered 8-byte gather, a quarter of this kernel's time from L2, a few
+    // cycles from LDS.  Ranges that need more than rows_cap rows are walked in chunks of
+    // (rows_cap - 1) * slots_per_row slots, re-staging in between.
     const uint32_t b_lo = (uint32_t)((u64)nbatch_total * part / nparts);
     const uint32_t b_hi = (uint32_t)((u64)nbatch_total * (part + 1) / nparts);
     const uint32_t *drow = dir + (size_t)bin * nbatch_total;
+    const uint32_t per_slot = nbatch_total / nslots;
+    const uint32_t spr = nslots / FL_PAL_H;                       // slots per palette row
+    const float inv_spr = 1.0f / (float)spr, inv_ps = 1.0f / (float)per_slot;
+    const uint32_t chunk_slots = (rows_cap - 1u) * spr;
 
-    // palette row of a batch = its slot * 64 / nslots (iter.hip); slots_per_row = nslots / 64 >= 16
-    const uint32_t spr = nslots / FL_PAL_H;
-    const float inv_spr = 1.0f / (float)spr;
-    for (uint32_t g0v = b_lo + wv * 64; g0v < b_hi; g0v += nwaves * 64) {
+    for (uint32_t cb = b_lo; cb < b_hi;) {
+    const uint32_t cs_lo = cb / per_slot;
+    const uint32_t ce = min(b_hi, (cs_lo + chunk_slots) * per_slot);
+    const uint32_t row_lo = cs_lo / spr, nrows = min(rows_cap, (uint32_t)FL_PAL_H - row_lo);
+    __syncthreads();                                               // readers of the previous chunk's rows are done
+    for (uint32_t i = tid; i < nrows * FL_PAL_W; i += blockDim.x) pal[i] = palette[row_lo * FL_PAL_W + i];
+    __syncthreads();
+    for (uint32_t g0v = cb + wv * 64; g0v < ce; g0v += nwaves * 64) {
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0v);      // wave-uniform
-        // batch id = batch_in_slot * nslots + slot: slot of the group's first batch, its row and the
-        // remainder, once per group (scalar); a lane's run r < 64 then adds (rem0 + r) / spr <= 4 rows
-        const uint32_t s0 = g0 % nslots, row0 = s0 / spr, rem0 = s0 - row0 * spr;
+        // slot of the group's first batch and the remainder, once per group (scalar); run r < 64 of
+        // the group then belongs to slot s0 + (rem0 + r) / per_slot
+        const uint32_t s0 = g0 / per_slot, rem0 = g0 - s0 * per_slot;
         // 64 directory entries per wave; their runs form one virtual array of `total` records
         const uint32_t batch = g0 + lane;
-        const uint32_t e = batch < b_hi ? drow[batch] : 0u;
+        const uint32_t e = batch < ce ? drow[batch] : 0u;
         const uint32_t c = e & 0xffffu, first = e >> 16;
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
@@ -131,18 +145,30 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 const int delta = (int)(m << 8) >> 8;                         // first[r] - excl[r], sign-extended
                 live[k] = v < total;
                 const uint32_t rbatch = g0 + r;
+#ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
+                rec[k] = live[k] ? ((rbatch * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u)) + (delta & 0) : 0u;
+#else
                 rec[k] = live[k] ? log[(size_t)rbatch * batch_records + (uint32_t)((int)v + delta)] : 0u;
-                const uint32_t rr = row0 + (uint32_t)(((float)(rem0 + r) + 0.5f) * inv_spr);
-                row[k] = rr >= FL_PAL_H ? rr - FL_PAL_H : rr;                    // the group may wrap past the last slot
+#endif
+                const uint32_t rslot = s0 + (uint32_t)(((float)(rem0 + r) + 0.5f) * inv_ps);     // exact: small integers
+                row[k] = live[k] ? (uint32_t)(((float)rslot + 0.5f) * inv_spr) - row_lo : 0u;     // row within the staged rows
             }
             u64 val[ILP];
 #pragma unroll
-            for (int k = 0; k < ILP; ++k) val[k] = palette[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+#ifdef ACC_X_NOPAL
+            for (int k = 0; k < ILP; ++k) val[k] = (1ull << 54) | row[k] | (rec[k] & 0xffu);
+#else
+            for (int k = 0; k < ILP; ++k) val[k] = pal[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+#endif
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
                 if (!live[k]) continue;
                 const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
+#ifdef ACC_X_NOATOM
+                const u64 old = tile[off ^ 1u]; if (val[k] == 0x1234567ull) tile[off] = old;
+#else
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 if ((uint32_t)(old >> 32) >= (256u << 23)) {
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
@@ -152,6 +178,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 }
             }
         }
+    }
+    cb = ce;
     }
     __syncthreads();
 
@@ -182,15 +210,22 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
                         uint32_t astride, uint32_t aheight, bool wide)
 {
+    // LDS: the tile, 64 marks per wave, and as many palette rows (2 KB each) as the slot range of one
+    // workgroup touches — capped by what lets two narrow workgroups (one wide) share a CU's 160 KB
+    const uint32_t spr = nslots / FL_PAL_H, slots_per_part = (nslots + nparts - 1) / nparts;
+    const uint32_t want = (slots_per_part + spr - 1) / spr + 1;
     if (wide) {
+        const uint32_t rows = want < 2u ? 2u : want > 12u ? 12u : want;
         static unsigned long long attr = 0;
         ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, attr);
-        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024), (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4, st,
-                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
+        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024),
+                           (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4 + rows * FL_PAL_W * 8, st,
+                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows);
         return;
     }
+    const uint32_t rows = want < 2u ? 2u : want > 5u ? 5u : want;
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
-    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4, st, log, dir, palette, atom, out4,
-                       tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight);
+    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
+                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows);
 }

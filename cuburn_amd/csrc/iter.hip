@@ -355,7 +355,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (++staged == bg.rounds || rd + 1 == nrounds) {
-                const uint32_t batch_id = batch_in_slot * gridDim.x + slot;
+                // slot-major: the batches of a slot are neighbours in the log and the directory, so a range
+                // of batch ids covers few slots, i.e. few palette rows (binned.hip stages them in LDS)
+                const uint32_t batch_id = slot * (bg.nbatch_total / gridDim.x) + batch_in_slot;
                 __syncthreads();
                 // Each thread takes its own staged records into registers (while wave 0 scans the
                 // tile counts), so that the scatter below can sort the batch IN PLACE: no second
