@@ -84,9 +84,6 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
 
-    for (uint32_t i = tid; i < CELLS; i += blockDim.x) tile[i] = 0ull;
-    mk[lane] = 0u;
-    __syncthreads();
 
     // This workgroup's contiguous range of batches.  Batch id = slot * per_slot + batch_in_slot
     // (iter.hip), so the range covers a narrow range of SLOTS, and with them of palette rows (row of
@@ -102,12 +99,29 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const float inv_spr = 1.0f / (float)spr, inv_ps = 1.0f / (float)per_slot;
     const uint32_t chunk_slots = (rows_cap - 1u) * spr;
 
+    if (b_lo >= b_hi) return;                                      // no batches for this part (tiny launches): nothing to add
     for (uint32_t cb = b_lo; cb < b_hi;) {
     const uint32_t cs_lo = cb / per_slot;
     const uint32_t ce = min(b_hi, (cs_lo + chunk_slots) * per_slot);
     const uint32_t row_lo = cs_lo / spr, nrows = min(rows_cap, (uint32_t)FL_PAL_H - row_lo);
+    // (the first chunk's rows are requested before the tile is zeroed: the workgroup's first global
+    // latency then runs under the zeroing instead of after it)
+    u64 stagev[3];                                                 // rows_cap * 256 <= 3 * blockDim.x
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint32_t i = tid + q * blockDim.x;
+        stagev[q] = i < nrows * FL_PAL_W ? palette[row_lo * FL_PAL_W + i] : 0ull;
+    }
+    if (cb == b_lo) {
+        for (uint32_t i = tid; i < CELLS; i += blockDim.x) tile[i] = 0ull;
+        mk[lane] = 0u;
+    }
     __syncthreads();                                               // readers of the previous chunk's rows are done
-    for (uint32_t i = tid; i < nrows * FL_PAL_W; i += blockDim.x) pal[i] = palette[row_lo * FL_PAL_W + i];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint32_t i = tid + q * blockDim.x;
+        if (i < nrows * FL_PAL_W) pal[i] = stagev[q];
+    }
     __syncthreads();
     for (uint32_t g0v = cb + wv * 64; g0v < ce; g0v += nwaves * 64) {
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0v);      // wave-uniform

@@ -126,6 +126,13 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
     code->resize(n);
     a.code(prog, code->data());
     a.destroy(&prog);
+    // FLAME_RTC_DUMP=<dir>: keep the generated header and the code object of the last compile, for
+    // llvm-objdump -d (tools/dump_spec_kernel.py)
+    if (const char *dir = getenv("FLAME_RTC_DUMP")) {
+        const std::string d(dir);
+        if (FILE *f = fopen((d + "/flame_spec.h").c_str(), "w")) { fwrite(header.data(), 1, header.size(), f); fclose(f); }
+        if (FILE *f = fopen((d + "/k_iter_spec.co").c_str(), "wb")) { fwrite(code->data(), 1, code->size(), f); fclose(f); }
+    }
     return 0;
 }
 
