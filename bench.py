@@ -300,7 +300,7 @@ def main():
             'config': {'workload': ('BASELINE configs[1]: 1920x1080 still, 3 xforms (linear+spherical+swirl), '
                                     '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out') if args.config == 'cfg2'
                        else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
-                            % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame),
+                            % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
                        'walker_waves': mgr.fb.nw,
                        'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
