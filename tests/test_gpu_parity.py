@@ -807,6 +807,27 @@ def test_4k_binned_equals_atomic(mgr):
     assert np.array_equal(dev_a, dev_b)
 
 
+@pytest.mark.parametrize('nw,size', [(8, (3840, 2160)), (16, (3840, 2160)), (16, (7680, 4320))])
+def test_large_images_large_workgroups_binned_equals_atomic(nw, size, monkeypatch, built):
+    """The geometries that ship above 1440p — 8- and 16-wave workgroups with the tile-count scan
+    shared by all waves (more than 512 tiles), narrow tiles at 4K and 256x64 tiles at 8K — against
+    direct atomics on the same device: packed histograms, counters and RNG states bit for bit."""
+    monkeypatch.setenv('FLAME_NW', str(nw))
+    m = render.RenderManager(device=0, nslots=1024, host_seed=44)
+    assert m.fb.nw == nw
+    gnm, prof = linear_flame()
+    prof = dict(prof, width=size[0], height=size[1])
+    gnm['camera']['scale'] = 0.6
+    res_a, _, dev_a, dim, seeds = run_device_model_gpu_only(m, gnm, prof, nrounds=19, fuse=5, mode=0)
+    res_b, _, dev_b, dim, _ = run_device_model_gpu_only(m, gnm, prof, nrounds=19, fuse=5, mode=1, seeds_in=seeds)
+    assert ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64) > 512
+    assert np.array_equal(res_a['ctr'][:2], res_b['ctr'][:2]) and int(res_a['ctr'][3]) == 0
+    assert np.array_equal(res_a['atom'], res_b['atom'])
+    assert int((res_a['atom'] >> np.uint64(54)).sum()) == int(res_a['ctr'][0]) > 0
+    assert np.array_equal(dev_a, dev_b)
+    m.fb.free()
+
+
 def run_device_model_gpu_only(mgr, gnm, prof, nrounds, fuse, mode, seeds_in=None):
     lib = _lib.load()
     if seeds_in is not None:
