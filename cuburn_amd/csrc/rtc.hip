@@ -110,6 +110,9 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #ifdef FL_SCAN_SERIAL_MAX
                           "-DFL_SCAN_SERIAL_MAX=" FL_STR(FL_SCAN_SERIAL_MAX),
 #endif
+#ifdef FL_CNT_SETS
+                          "-DFL_CNT_SETS=" FL_STR(FL_CNT_SETS),
+#endif
 #ifdef FL_ITER_NO_SLP
                           "-fno-slp-vectorize",
 #endif
