@@ -32,7 +32,10 @@
 #define FL_SCAN_SERIAL_MAX 8u
 #endif
 #ifndef FL_CNT_SETS
-#define FL_CNT_SETS 2          /* sets of tile counters per workgroup (LDS: one more array of tiles + 1 words each) */
+#define FL_CNT_SETS 3          /* sets of tile counters per 4-wave workgroup (LDS: an array of tiles + 1 words each) */
+#endif
+#ifndef FL_CNT_SETS_BIG
+#define FL_CNT_SETS_BIG 2      /* the same for 8- and 16-wave workgroups (many tiles: scanning more sets costs more than it saves) */
 #endif
 
 template <int NW>
@@ -197,6 +200,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
           uint32_t *__restrict__ bin_log, uint32_t *__restrict__ bin_dir)
 {
     constexpr int NT = NW * 64;
+    constexpr int SETS = NW == 4 ? FL_CNT_SETS : FL_CNT_SETS_BIG;
     constexpr bool BINNED = ACC == 1 || ACC == 3, WIDE = ACC == 3;
     constexpr uint32_t TWL = WIDE ? FL_TILE_W_WIDE_LOG2 : 7u;          // log2 of the tile width
     constexpr uint32_t PAY_BITS = TWL + FL_TILE_H_LOG2 + 8u;          // row | column | palette column
@@ -206,16 +210,14 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + 2 * 3 * NT * 4);             // [R*NT]  (binned)
     uint16_t *skey = reinterpret_cast<uint16_t *>(stage + bg.rounds * NT);             // [R*NT]  (wide only)
     uint32_t *cnt = stage + bg.rounds * NT + (WIDE ? bg.rounds * NT / 2 : 0);          // [B+1]
-    // FL_CNT_SETS sets of tile counters / scatter cursors, lane l uses set l % FL_CNT_SETS: the lanes of
-    // a wave hit few distinct tiles, and LDS atomics on one address are applied one lane at a time —
-    // several sets cut those chains (k_iter 0.80 -> 0.73 ms with two).  The cursors of sets 1.. take the
-    // place of their counters once the scan has run; set 0's cursors have their own array.
+    // SETS sets of tile counters, lane l uses set l % SETS: the lanes of a wave hit few
+    // distinct tiles, and LDS atomics on one address are applied one lane at a time — several sets
+    // cut those chains (k_iter 0.80 -> 0.73 ms with two).  After the scan the scatter cursors of a
+    // set take the place of its counters (zeroed again once the batch has been scattered).
     const uint32_t CNTW = (bg.nbins + 1 + 3) & ~3u;
-    uint32_t *cur = cnt + FL_CNT_SETS * CNTW;                                           // [B+1] set 0's cursors
-    uint32_t *s_nvalid = cur + CNTW;                                                    // [4]
+    uint32_t *s_nvalid = cnt + SETS * CNTW;                                      // [4]
     uint32_t *tot = s_nvalid + 4;                                                      // [128] totals of 64-tile chunks
-    const uint32_t my_set = (threadIdx.x & 63u) % FL_CNT_SETS;
-    uint32_t *my_cnt = cnt + my_set * CNTW, *my_cur = my_set ? my_cnt : cur;
+    uint32_t *my_cnt = cnt + ((threadIdx.x & 63u) % SETS) * CNTW;
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const uint32_t slot = blockIdx.x, ts = slot, prow = slot * FL_PAL_H / gridDim.x;
@@ -230,7 +232,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     const float *__restrict__ P = params + (size_t)ts * pstride;
 
     if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[prow * FL_PAL_W + i];
-    if (BINNED) for (uint32_t i = tid; i < FL_CNT_SETS * CNTW; i += NT) cnt[i] = 0;
+    if (BINNED) for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;
     uint32_t staged = 0, batch_in_slot = 0;
 
     const size_t wi = (size_t)slot * NT + tid;
@@ -390,16 +392,15 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                         uint32_t running = 0;
                         for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
                             const uint32_t b = c0 + l;
-                            uint32_t vs[FL_CNT_SETS], v = 0;
+                            uint32_t vs[SETS], v = 0;
 #pragma unroll
-                            for (int t = 0; t < FL_CNT_SETS; ++t) { vs[t] = b <= bg.nbins ? cnt[t * CNTW + b] : 0u; v += vs[t]; }
+                            for (int t = 0; t < SETS; ++t) { vs[t] = b <= bg.nbins ? cnt[t * CNTW + b] : 0u; v += vs[t]; }
                             const uint32_t incl = wave_incl_scan(v, l);
                             const uint32_t excl = incl - v + running;
                             if (b <= bg.nbins) {
-                                cur[b] = excl; cnt[b] = 0;
-                                uint32_t at = excl + vs[0];
+                                uint32_t at = excl;
 #pragma unroll
-                                for (int t = 1; t < FL_CNT_SETS; ++t) { cnt[t * CNTW + b] = at; at += vs[t]; }
+                                for (int t = 0; t < SETS; ++t) { cnt[t * CNTW + b] = at; at += vs[t]; }
                             }
                             if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
                             if (b == bg.nbins) *s_nvalid = excl;
@@ -411,9 +412,8 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                     const uint32_t b = c * 64u + l;
                     uint32_t v = 0;
 #pragma unroll
-                    for (int t = 0; t < FL_CNT_SETS; ++t) v += b <= bg.nbins ? cnt[t * CNTW + b] : 0u;
+                    for (int t = 0; t < SETS; ++t) v += b <= bg.nbins ? cnt[t * CNTW + b] : 0u;
                     const uint32_t incl = wave_incl_scan(v, l);
-                    if (b <= bg.nbins) cur[b] = incl - v;
                     if (l == 63u) tot[c] = incl;
                 }
                 __syncthreads();
@@ -426,13 +426,14 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                         const uint32_t base = c < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)(i0 - t0), c)
                                                       : (uint32_t)__builtin_amdgcn_readlane((int)(i1 - t1), c - 64u);
                         const uint32_t b = c * 64u + l;
-                        if (b <= bg.nbins) {
-                            const uint32_t excl = cur[b] + base;
-                            uint32_t at = excl + cnt[b];
-                            cur[b] = excl; cnt[b] = 0u;
+                        uint32_t vs[SETS], v = 0;                  // (the chunk is scanned again rather than stored in between)
 #pragma unroll
-                            for (int t = 1; t < FL_CNT_SETS; ++t) { const uint32_t vt = cnt[t * CNTW + b]; cnt[t * CNTW + b] = at; at += vt; }
-                            const uint32_t v = at - excl;
+                        for (int t = 0; t < SETS; ++t) { vs[t] = b <= bg.nbins ? cnt[t * CNTW + b] : 0u; v += vs[t]; }
+                        const uint32_t excl = wave_incl_scan(v, l) - v + base;
+                        if (b <= bg.nbins) {
+                            uint32_t at = excl;
+#pragma unroll
+                            for (int t = 0; t < SETS; ++t) { cnt[t * CNTW + b] = at; at += vs[t]; }
                             if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
                             else *s_nvalid = excl;
                         }
@@ -449,7 +450,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (k2[q0 + q] != 0xffffffffu)
-                            pos[q] = __hip_atomic_fetch_add(my_cur + k2[q0 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            pos[q] = __hip_atomic_fetch_add(my_cnt + k2[q0 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (k2[q0 + q] != 0xffffffffu) stage[pos[q]] = r2[q0 + q] & ((1u << PAY_BITS) - 1u);
@@ -459,7 +460,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
                 const uint4 *src = reinterpret_cast<const uint4 *>(stage);
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
-                for (uint32_t i = tid; i < (FL_CNT_SETS - 1) * CNTW; i += NT) cnt[CNTW + i] = 0;   // cursors of sets 1.. become counters again
+                for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
                 staged = 0; ++batch_in_slot;
                 __syncthreads();
             }
@@ -577,7 +578,7 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
-    if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + (FL_CNT_SETS + 1) * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16
+    if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + (nw == 4 ? FL_CNT_SETS : FL_CNT_SETS_BIG) * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16
              + (((nbins + 64u) >> 6) > FL_SCAN_SERIAL_MAX ? 128 * 4 : 0);      // chunk totals: only the all-waves scan uses them
     else b += FL_PAL_W * 8;
     return b;

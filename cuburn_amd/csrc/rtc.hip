@@ -113,6 +113,9 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #ifdef FL_CNT_SETS
                           "-DFL_CNT_SETS=" FL_STR(FL_CNT_SETS),
 #endif
+#ifdef FL_CNT_SETS_BIG
+                          "-DFL_CNT_SETS_BIG=" FL_STR(FL_CNT_SETS_BIG),
+#endif
 #ifdef FL_ITER_NO_SLP
                           "-fno-slp-vectorize",
 #endif
