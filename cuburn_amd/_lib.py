@@ -40,6 +40,7 @@ _SIGS = {
     'fl_filter': (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
     'fl_output': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64]),
     'fl_output_bytes': (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_int]),
+    'fl_sort_u32': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     'fl_frame_begin': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     'fl_frame_ms': (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     'fl_frame_query': (C.c_int, [C.c_void_p, C.c_uint32]),

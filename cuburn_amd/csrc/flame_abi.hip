@@ -75,6 +75,7 @@ struct fl_ctx {
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
     float4 *d_points = nullptr;       // [nslots*NT]
     u64 *d_counters = nullptr;
+    uint32_t *d_sort = nullptr; size_t sort_words = 0;     // radix sort scratch (grow-only): digit counts + chunk totals
     uint32_t bin_rounds = 16, bin_parts = 0;      // bin_parts 0: chosen per image (see do_iter_launch)
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
@@ -310,7 +311,7 @@ void fl_ctx_destroy(fl_ctx *c)
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
         if (c->own_stream && ln.stream) hipStreamDestroy(ln.stream);
     }
-    hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters);
+    hipFree(c->d_rng); hipFree(c->d_points); hipFree(c->d_counters); hipFree(c->d_sort);
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (uint32_t i = 0; i < fl_ctx::kFrames; ++i) {
         if (c->ev_begin_[i]) hipEventDestroy(c->ev_begin_[i]);
@@ -876,6 +877,32 @@ int fl_output(fl_ctx *c, uint32_t w, uint32_t h, int fmt, void *host_out, uint64
     L(c).out_rec = true;
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, dst, fl_output_bytes(w, h, fmt), hipMemcpyDeviceToHost, L(c).stream));
     if (c->frame_seq) HIPCHK(hipEventRecord(c->ev_end_[(c->frame_seq - 1) % fl_ctx::kFrames], L(c).stream));
+    return FL_OK;
+}
+
+int fl_sort_u32(fl_ctx *c, uint64_t dst_dev, uint64_t src_dev, uint32_t n, uint32_t lo_bit, uint32_t nbits, int ignore_max,
+                uint32_t *nvalid)
+{
+    REQUIRE(c && dst_dev && src_dev && dst_dev != src_dev, "null or aliased key arrays");
+    REQUIRE(nbits >= 1 && nbits <= 10 && lo_bit + nbits <= 32, "a pass sorts 1..10 bits inside the 32-bit key");
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) { if (nvalid) *nvalid = 0; return FL_OK; }
+    size_t chunk_words = 0;
+    const size_t hist_words = sort_scratch_words(n, nbits, &chunk_words), need = hist_words + chunk_words;
+    if (need > c->sort_words) {
+        HIPCHK(hipStreamSynchronize(L(c).stream));
+        hipFree(c->d_sort); c->d_sort = nullptr; c->sort_words = 0;
+        HIPCHK(hipMalloc(&c->d_sort, need * 4));
+        c->sort_words = need;
+    }
+    uint32_t *chunk_tot = c->d_sort + hist_words, *total_dev = chunk_tot + (chunk_words - 1);
+    launch_sort_pass(L(c).stream, (uint32_t *)(uintptr_t)dst_dev, (const uint32_t *)(uintptr_t)src_dev, n, lo_bit, nbits,
+                     ignore_max, c->d_sort, chunk_tot, total_dev);
+    HIPCHK(hipGetLastError());
+    if (nvalid) {                                           // the reference leaves this count on the device (sort.py:449-452)
+        HIPCHK(hipMemcpyAsync(nvalid, total_dev, 4, hipMemcpyDeviceToHost, L(c).stream));
+        HIPCHK(hipStreamSynchronize(L(c).stream));
+    }
     return FL_OK;
 }
 

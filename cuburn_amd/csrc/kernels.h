@@ -92,3 +92,9 @@ void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src,
 
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);
+
+// sort.hip: one stable radix pass (nbits <= 10 at lo_bit) over n keys; hist = scratch of
+// sort_scratch_words() words, chunk_tot = *chunk_words words (the last one receives the number of keys kept)
+int launch_sort_pass(hipStream_t st, uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t lo_bit, uint32_t nbits,
+                     int ignore_max, uint32_t *hist, uint32_t *chunk_tot, uint32_t *total_dev);
+size_t sort_scratch_words(uint32_t n, uint32_t nbits, size_t *chunk_words);

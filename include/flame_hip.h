@@ -211,6 +211,17 @@ enum {
 size_t fl_output_bytes(uint32_t w, uint32_t h, int fmt);   /* 0 for an unknown format */
 int fl_output(fl_ctx *ctx, uint32_t w, uint32_t h, int fmt, void *host_out, uint64_t dev_out);
 
+/* cuburn/code/sort.py:443-504 Sorter.sort: one radix pass over n 32-bit keys on the device —
+ * dst = src ordered by the `nbits` (1..10) bits from lo_bit up, keys with equal digits in their
+ * original order (stable: passes from the low digit up compose into a full sort; the reference's
+ * pass is not stable and its multi-pass sort is marked broken, sort.py:437-441,455-458).
+ * ignore_max: keys equal to 0xffffffff are dropped (sort.py:449-452); *nvalid (optional, makes the
+ * call synchronous) receives the number of keys written.  dst and src are device addresses and must
+ * not overlap; the pass runs on the context's current stream.  Not used by the render path — like
+ * the reference's sorter (imported by render.py:19, never called). */
+int fl_sort_u32(fl_ctx *ctx, uint64_t dst_dev, uint64_t src_dev, uint32_t n, uint32_t lo_bit, uint32_t nbits, int ignore_max,
+                uint32_t *nvalid);
+
 /* cuburn/render.py:404,430 timing_event / DurationEvent: fl_frame_begin opens a frame and returns
  * its id; fl_output closes it.  fl_frame_ms blocks until that frame is done and gives the ms
  * between the two (DurationEvent.time, render.py:26-38); fl_frame_query is DurationEvent.query
