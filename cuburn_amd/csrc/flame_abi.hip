@@ -529,11 +529,9 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
 {
     size_t nbins = (size_t)d.ah * d.astride;
     // cuburn/render.py:321-328
-    HIPCHK(hipMemsetAsync(L(c).d_front, 0, 16 * nbins, L(c).stream));
-    HIPCHK(hipMemsetAsync(L(c).d_atom, 0, 8 * nbins, L(c).stream));
-    HIPCHK(hipMemsetAsync(L(c).d_hot, 0, 4 * (nbins / 16), L(c).stream));
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 32, L(c).stream));
-    if (reset_points) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c->d_points, 0x7fc00000, (size_t)c->nslots * c->nw * 64 * 4, L(c).stream));
+    launch_clear_frame(L(c).stream, L(c).d_front, L(c).d_atom, L(c).d_hot, c->d_counters, c->d_points, (uint32_t)nbins,
+                       reset_points ? c->nslots * (uint32_t)c->nw * 64u : 0u);
+    HIPCHK(hipGetLastError());
     return FL_OK;
 }
 

@@ -26,6 +26,8 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  uint32_t *log, uint32_t *dir,
                  hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot);
+void launch_clear_frame(hipStream_t st, float4 *front, u64 *atom, uint32_t *hot, u64 *counters, float4 *points,
+                        uint32_t nbins, uint32_t npoints);      // npoints = 0: the walkers are left alone
 void launch_shuffle_tap(hipStream_t st, int nw, uint32_t *out, uint32_t round);
 void launch_apply_xf_tap(hipStream_t st, const int32_t *prog, const float *params, uint32_t ts, int xfi,
                          uint32_t n, float4 *pts, fl_mwc *rng);
