@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cmath>
 #include <string>
+#include <atomic>
 #include <vector>
 #include <algorithm>
 #include "kernels.h"
@@ -50,6 +51,7 @@ struct Lane {
     hipStream_t aux = nullptr;
     hipEvent_t ev_it[2] = {nullptr, nullptr}, ev_ac[2] = {nullptr, nullptr};   // iterate k queued / drains of launch k done
     float *d_params = nullptr;        // [nslots * pstride] one block per temporal sample = per walker slot (grow-only)
+    uint64_t params_serial = 0;       // serial of the genome whose parameters the blocks hold (0: none / just allocated)
     size_t params_floats = 0;
     u64 *d_palette = nullptr;         // [FL_PAL_H * FL_PAL_W]
     // cross-lane ordering of the state both lanes share
@@ -94,6 +96,7 @@ struct fl_ctx {
 #define FL_NOUT 65536u                // RNG states reserved for the output dither kernel
 
 struct fl_genome {
+    uint64_t serial = 0;                    // unique per created genome (a lane remembers whose parameters its blocks hold)
     std::vector<int32_t> prog;
     IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
     hipFunction_t rtc_fn[3][2][4] = {};     // [nw 4 / 8 / 16][count][acc] once compiled
@@ -421,6 +424,7 @@ int fl_genome_create(fl_ctx *c, const int32_t *prog, uint32_t nprog, const int32
         for (int v : spec.vids[i]) REQUIRE(v >= 0, "variation record without a variation number");
     HIPCHK(hipSetDevice(c->device));
     fl_genome *g = new fl_genome;
+    { static std::atomic<uint64_t> next_serial{1}; g->serial = next_serial.fetch_add(1); }
     g->spec = spec;
     g->prog.assign(prog, prog + nprog);
     g->nops = nops; g->nrows = nrows; g->pstride = ps;
@@ -512,13 +516,14 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
         HIPCHK(hipStreamSynchronize(L(c).stream));
         hipFree(L(c).d_params); L(c).d_params = nullptr; L(c).params_floats = 0;
         HIPCHK(hipMalloc(&L(c).d_params, sizeof(float) * need));
-        L(c).params_floats = need;
+        L(c).params_floats = need; L(c).params_serial = 0;
     }
     fl_mwc *rng_pal = c->d_rng + (size_t)c->nslots * c->nw * 64;
     { int rc = wait_other(c, 0); if (rc) return rc; }     // palette RNG states are shared
     launch_interp_palette(L(c).stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, L(c).d_palette);
     launch_interp_params(L(c).stream, L(c).d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
-                         c->nslots, ts, td / (float)c->nslots, d);
+                         c->nslots, ts, td / (float)c->nslots, d, L(c).params_serial != g->serial);
+    L(c).params_serial = g->serial;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L(c).ev_interp_done, L(c).stream));
     L(c).interp_rec = true;
@@ -1022,6 +1027,7 @@ int fl_write_buffer(fl_ctx *c, fl_genome *g, int which, const void *src, size_t 
     REQUIRE(nbytes <= cap, "write larger than buffer");
     sync_all(c);
     HIPCHK(hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice));
+    if (which == FL_BUF_PARAMS) L(c).params_serial = 0;       // whatever was written, the next fl_interp starts from zeroed blocks
     return FL_OK;
 }
 

@@ -166,9 +166,12 @@ void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes,
 }
 
 void launch_interp_params(hipStream_t st, float *params, const float *times, const float *knots,
-                          const int32_t *ops, uint32_t nops, uint32_t pstride, uint32_t nts, float ts, float tstep, fl_dim dim)
+                          const int32_t *ops, uint32_t nops, uint32_t pstride, uint32_t nts, float ts, float tstep, fl_dim dim,
+                          bool zero_first)
 {
-    hipMemsetAsync(params, 0, sizeof(float) * (size_t)nts * pstride, st);     // padding / unused post affines
+    // padding / unused post affines read as zero.  The ops of a genome write the same words every
+    // frame, so the fill is only needed when the blocks last held another genome's parameters.
+    if (zero_first) hipMemsetAsync(params, 0, sizeof(float) * (size_t)nts * pstride, st);
     if (nops == 0) return;
     hipLaunchKernelGGL(k_interp_params, dim3((nts + 255) / 256, nops), dim3(256), 0, st, params, times, knots,
                        (const int4 *)ops, nops, pstride, nts, ts, tstep, dim);

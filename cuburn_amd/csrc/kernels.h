@@ -63,7 +63,7 @@ void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes,
                            float ts, float tstep, u64 *out);
 void launch_interp_params(hipStream_t st, float *params, const float *times, const float *knots,
                           const int32_t *ops, uint32_t nops, uint32_t pstride, uint32_t nts, float ts, float tstep,
-                          fl_dim dim);
+                          fl_dim dim, bool zero_first);
 
 // filters.hip
 void launch_yuv_to_rgb(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
