@@ -20,15 +20,29 @@ k_f32_to_rgba(fl_dim d, const float4 *__restrict__ src, fl_mwc *__restrict__ rng
     if (t >= nrng) return;
     mwc_t r = {rng[t].mul, rng[t].state, rng[t].carry};
     const uint32_t npix = d.w * d.h;
-    for (uint32_t p = t; p < npix; p += nrng) {
-        const uint32_t x = p % d.w, y = p / d.w;
-        const float4 in = src[(size_t)d.astride * (y + FL_GUTTER) + x + FL_GUTTER];   // output.py:28
-        T4 o;
-        o.x = (T)dclampf(r, (float)PEAK, in.x);
-        o.y = (T)dclampf(r, (float)PEAK, in.y);
-        o.z = (T)dclampf(r, (float)PEAK, in.z);
-        o.w = (T)dclampf(r, (float)PEAK, in.w);
-        dst[p] = o;
+    // Only nrng threads exist (one RNG state each, 4 waves per CU), so the kernel is bound by the
+    // latency of its loads: four pixels are requested at a time (eight measure the same), then dithered in order (the draws of a
+    // state are consumed in the same order as before).
+    for (uint32_t p0 = t; p0 < npix; p0 += 4u * nrng) {
+        float4 in[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = p0 + k * nrng, pc = p < npix ? p : t;
+            const uint32_t x = pc % d.w, y = pc / d.w;
+            in[k] = src[(size_t)d.astride * (y + FL_GUTTER) + x + FL_GUTTER];        // output.py:28
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t p = p0 + k * nrng;
+            if (p < npix) {
+                T4 o;
+                o.x = (T)dclampf(r, (float)PEAK, in[k].x);
+                o.y = (T)dclampf(r, (float)PEAK, in[k].y);
+                o.z = (T)dclampf(r, (float)PEAK, in[k].z);
+                o.w = (T)dclampf(r, (float)PEAK, in[k].w);
+                dst[p] = o;
+            }
+        }
     }
     rng[t].mul = r.mul; rng[t].state = r.state; rng[t].carry = r.carry;
 }
