@@ -39,6 +39,7 @@
 // traffic the packed form needs; 1024-thread workgroups at <= 64 VGPRs keep 8 waves per SIMD.
 #include "flame_device.h"
 #include "kernels.h"
+#include "tone_device.h"
 #include <utility>
 #include <cmath>
 
@@ -265,10 +266,31 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     res = make_float4(ox * rn, oy * rn, oz * rn, wn);
 }
 
-template <int P>
+// Normalise the accumulator into N (first pass input); with YUV -> RGB in front when the chain starts with `yuv`
+__device__ __forceinline__ float4 de_yuv_px(float4 p)       // cuburn/code/filters.py:71-77 + cuburn/code/color.py:25-40
+{
+    const float u = p.y - 0.5f * p.w, v = p.z - 0.5f * p.w;
+    return make_float4(fmaxf(0.0f, p.x + 1.402f * v), fmaxf(0.0f, p.x - 0.34414f * u - 0.71414f * v), fmaxf(0.0f, p.x + 1.772f * u), p.w);
+}
+// IN: what the first direction finds in `N`: 0 = the normalised image (x/w, y/w, z/w, w); 1 = the raw
+// accumulator, normalised as it is staged; 2 = the raw accumulator in YUV (the chain starts with `yuv`).
+// OUT: 1 = the last direction un-normalises its result and applies the tone filters that follow the DE
+// in the chain (DeTail) as it stores it.  Both run the per-pixel device functions of the separate
+// kernels (k_de_normalise, k_de_finish_tone) in the same order: bit-identical results, two passes over
+// the image and two launches less.
+template <int IN>
+__device__ __forceinline__ float4 de_in_px(float4 p)
+{
+    if (IN == 0) return p;
+    if (IN == 2) p = de_yuv_px(p);
+    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
+    return make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
+}
+
+template <int P, int IN, int OUT>
 __global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
 k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
-         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles)
+         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
 {
     using G = DeGeo<P>;
     static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
@@ -302,7 +324,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
         const int gx = de_clampi(bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, 0, xmax);
         const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
-        tn[it] = N[(uint32_t)(gy * (int)d.astride + gx)];
+        tn[it] = de_in_px<IN>(N[(uint32_t)(gy * (int)d.astride + gx)]);
     }
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
@@ -404,16 +426,17 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     else de_tap_loop<P, 0>(sA, sB, ci, cb, cs2, spk, res);
 
     const int xo = bx0 + ((ou * G::K) >> 1) + ov, yo = by0 + ou;
-    if (xo >= 0 && xo <= xmax && yo <= ymax)                        // the parallelogram sticks out of the image at both ends of a band
+    if (xo >= 0 && xo <= xmax && yo <= ymax) {                      // the parallelogram sticks out of the image at both ends of a band
+        if (OUT) {                                                  // as k_de_finish_tone (filters.hip)
+            float4 p = make_float4(res.x * res.w, res.y * res.w, res.z * res.w, res.w);
+            if (tail.do_log) p = logscale_px(p, tail.k1, tail.k2);
+            if (tail.do_clip) p = colorclip_px(p, tail.vib, tail.highpow, tail.gam, tail.lin, tail.lingam);
+            res = p;
+        }
         Nout[(uint32_t)(yo * (int)d.astride + xo)] = res;
+    }
 }
 
-// Normalise the accumulator into N (first pass input); with YUV -> RGB in front when the chain starts with `yuv`
-__device__ __forceinline__ float4 de_yuv_px(float4 p)       // cuburn/code/filters.py:71-77 + cuburn/code/color.py:25-40
-{
-    const float u = p.y - 0.5f * p.w, v = p.z - 0.5f * p.w;
-    return make_float4(fmaxf(0.0f, p.x + 1.402f * v), fmaxf(0.0f, p.x - 0.34414f * u - 0.71414f * v), fmaxf(0.0f, p.x + 1.772f * u), p.w);
-}
 template <bool YUV>
 __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__restrict__ N, const float4 *__restrict__ src)
 {
@@ -425,22 +448,24 @@ __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__rest
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
 }
 
-template <int P>
+template <int P, int IN, int OUT>
 static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
-                              float cs2, float ads, float dpow, float gspeed)
+                              float cs2, float ads, float dpow, float gspeed, DeTail tail)
 {
     using G = DeGeo<P>;
     static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
     static unsigned long long attr = 0;
-    ensure_max_dynamic_lds((const void *)k_de_dir<P>, attr);
+    ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL(k_de_dir<P>, dim3(8 * ((ntiles + 7) / 8)), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
-                       cs2, ads, dpow, gspeed, tiles_y, ntiles);
+    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
+                       cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
 }
 
+// in_mode (pattern 0 only): 0 = N holds the normalised image, 1 = the raw accumulator, 2 = the raw YUV
+// accumulator.  tail (pattern 7 only, may be null): un-normalise + the tone filters riding along.
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed)
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail)
 {
     DeCoefs kc;
     for (int i = 0; i < 7; ++i) kc.k[i] = coefs7[i];
@@ -449,8 +474,19 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     for (int r = 0; r < 16; ++r) spk.s[r] = expf((float)(r * r) / (-1.41421353816986f * sstd));
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
-#define DE(P) case P: launch_de_dir_one<P>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed); break
-    switch (pattern) { DE(0); DE(1); DE(2); DE(3); DE(4); DE(5); DE(6); DE(7); default: break; }
+    const DeTail none = {};
+#define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none)
+    switch (pattern) {
+    case 0: if (in_mode == 2) DE(0, 2, 0); else if (in_mode == 1) DE(0, 1, 0); else DE(0, 0, 0); break;
+    case 1: DE(1, 0, 0); break;
+    case 2: DE(2, 0, 0); break;
+    case 3: DE(3, 0, 0); break;
+    case 4: DE(4, 0, 0); break;
+    case 5: DE(5, 0, 0); break;
+    case 6: DE(6, 0, 0); break;
+    case 7: if (tail) DE(7, 0, 1); else DE(7, 0, 0); break;
+    default: break;
+    }
 #undef DE
 }
 

@@ -64,6 +64,10 @@ struct Lane {
     bool pend_yuv = false, pend_finish = false, pend_log = false;
     const float4 *pend_N = nullptr;
     float pend_k1 = 0.0f, pend_k2 = 0.0f;
+    // ... or, in the one-kernel-per-direction form, the LAST DIRECTION itself is still to run: it reads
+    // pend_N, un-normalises and tone-maps as it stores into d_front (de.hip, OUT = 1)
+    bool pend_last = false;
+    float pend_dp[5] = {0, 0, 0, 0, 0}, pend_k7[7] = {0, 0, 0, 0, 0, 0, 0};
     fl_dim pend_dim = {0, 0, 0, 0, 0};
 };
 
@@ -88,7 +92,7 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false;
+    bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
 };
 #define L(c) ((c)->lanes[(c)->cur])
@@ -180,7 +184,7 @@ static void free_fb(fl_ctx *c)
     hipFree(L(c).d_atom); hipFree(L(c).d_hot); hipFree(L(c).d_outpix);
     L(c).d_front = L(c).d_back = L(c).d_side = nullptr; L(c).d_blur = nullptr; L(c).d_atom = nullptr;
     L(c).d_hot = nullptr; L(c).d_outpix = nullptr; L(c).nbins = 0; L(c).outpix_bytes = 0;
-    L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = false;      // whatever was deferred dies with the buffers
+    L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = L(c).pend_last = false;      // whatever was deferred dies with the buffers
     L(c).pend_N = nullptr;
 }
 
@@ -241,6 +245,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
+    c->env_de_unfused_ends = env_on("FLAME_DE_UNFUSED_ENDS");   // separate normalise / un-normalise passes around the 8 directions
     c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
@@ -718,6 +723,21 @@ static void gauss7(float stdev, float *c)      // cuburn/filters.py:11-16
 // Anything else that looks at the buffers (another filter, output, the debug taps, the next
 // frame) first runs what is pending, so the observable behaviour is that of the separate kernels
 // (the fused kernels run the same per-pixel device functions in the same order).
+// The pending end of the DE: un-normalise (+ logscale if one was deferred, + colorclip if `clip` is
+// given) into d_front — through the last direction's kernel when that is what is pending.
+static void run_de_finish(fl_ctx *c, const float *clip)
+{
+    Lane &ln = L(c);
+    if (ln.pend_last) {
+        DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
+                    clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
+        launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, ln.pend_N, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
+                      ln.pend_dp[3], ln.pend_dp[4], 0, &t);
+    } else
+        launch_de_finish_tone(ln.stream, ln.pend_dim, ln.d_front, ln.pend_N, ln.pend_log, ln.pend_k1, ln.pend_k2, clip != nullptr, clip);
+    ln.pend_finish = ln.pend_log = ln.pend_last = false;
+}
+
 static void flush_pending(fl_ctx *c)
 {
     Lane &ln = L(c);
@@ -726,10 +746,7 @@ static void flush_pending(fl_ctx *c)
         std::swap(ln.d_front, ln.d_back);
         ln.pend_yuv = false;
     }
-    if (ln.pend_finish) {
-        launch_de_finish_tone(ln.stream, ln.pend_dim, ln.d_front, ln.pend_N, ln.pend_log, ln.pend_k1, ln.pend_k2, false, nullptr);
-        ln.pend_finish = ln.pend_log = false;
-    }
+    if (ln.pend_finish) run_de_finish(c, nullptr);
 }
 
 int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_t np)
@@ -764,13 +781,29 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         if (!c->env_de_split) {
             // One kernel per direction (de.hip): N ping-pongs between the back and front buffers
             float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-            launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
+            if (c->env_de_unfused_ends) {      // separate normalising / un-normalising passes (the form the fused ends are tested against)
+                launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
+                L(c).pend_yuv = false;
+                for (int pat = 0; pat < 8; ++pat) {
+                    launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
+                    std::swap(Na, Nb);
+                }
+                L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
+                break;
+            }
+            // The first direction normalises the accumulator (after `yuv`, if that is pending) as it stages
+            // it: front -> back; directions 1..6 ping-pong; the last one (back -> front) is left pending
+            // so that it can un-normalise and take a following logscale / colorclip with it.
+            launch_de_dir(st, d, 0, Na, Nb, k7, p[0], p[1], p[2], p[3], p[4], L(c).pend_yuv ? 2 : 1, nullptr);
             L(c).pend_yuv = false;
-            for (int pat = 0; pat < 8; ++pat) {
+            for (int pat = 1; pat < 7; ++pat) {
                 launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb);
             }
-            L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
+            // six swaps: the image sits in Na == d_back again
+            L(c).pend_finish = L(c).pend_last = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
+            for (int i = 0; i < 5; ++i) L(c).pend_dp[i] = p[i];
+            for (int i = 0; i < 7; ++i) L(c).pend_k7[i] = k7[i];
             break;
         }
         {
@@ -800,8 +833,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     case FL_FILT_COLORCLIP:
         REQUIRE(np >= 5, "colorclip needs vib,highpow,gam,lin,lingam");
         if (L(c).pend_finish && !L(c).pend_yuv) {
-            launch_de_finish_tone(st, d, L(c).d_front, L(c).pend_N, L(c).pend_log, L(c).pend_k1, L(c).pend_k2, true, p);
-            L(c).pend_finish = L(c).pend_log = false;
+            run_de_finish(c, p);
             ran_finish = true;
             break;
         }

@@ -241,8 +241,8 @@ void fl_host_free(void *p);
 int fl_timings_reset(fl_ctx *ctx);
 int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *niter_launches);
 /* The same, split further: ms[0] iterate kernels, [1] tile accumulate, [2] flush, [3] all fl_filter calls,
- * [4] the DE proper (normalise + 8 directions of FL_FILT_BILATERAL), [5] the call that un-normalised the DE result
- * (with logscale / colorclip riding along when they follow directly). */
+ * [4] the DE proper (FL_FILT_BILATERAL: seven directions, the first normalising the accumulator), [5] the call that
+ * un-normalised the DE result (the last direction, with logscale / colorclip riding along when they follow directly). */
 int fl_timings_detail(fl_ctx *ctx, float ms[6]);
 
 /* ---- debug taps (tests only): read/write device state ---- */

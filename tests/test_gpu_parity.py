@@ -1083,3 +1083,31 @@ def test_deferred_filter_fusion_is_bit_identical(mgr):
         a, b = run(chain, False), run(chain, True)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), chain
         assert np.isfinite(a).all()
+
+
+def test_de_fused_ends_equal_separate_passes(mgr, monkeypatch):
+    """The first DE direction normalises the accumulator as it stages it and the last one
+    un-normalises / tone-maps as it stores (de.hip IN / OUT): same bits as the separate
+    k_de_normalise and k_de_finish_tone passes around eight plain directions (FLAME_DE_UNFUSED_ENDS=1)."""
+    lib = _lib.load()
+    dim = mgr.fb.calc_dim(FW, FH)
+    buf = synth_accum(dim)
+    steps = {'yuv': [], 'bilateral': [6.0 * FW / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
+             'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)]}
+
+    def run(m, chain):
+        _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
+        m.fb.write('front', buf)
+        for name in chain:
+            arr = np.asarray(steps[name], np.float32)
+            _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
+        return m.fb.read('front', buf.shape, np.float32)
+
+    monkeypatch.setenv('FLAME_DE_UNFUSED_ENDS', '1')
+    sep = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
+    for chain in (['yuv', 'bilateral', 'logscale', 'colorclip'], ['bilateral'], ['yuv', 'bilateral', 'logscale'],
+                  ['bilateral', 'colorclip']):
+        a, b = run(mgr, chain), run(sep, chain)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), chain
+        assert np.isfinite(a).all() and a.max() > 0
+    sep.fb.free()
