@@ -129,8 +129,8 @@ def copy_bandwidth(torch, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--cpu-seconds', type=float, default=16.0, help='CPU baseline budget (0 = skip)')
     ap.add_argument('--preheat-seconds', type=float, default=3.0,
@@ -209,9 +209,20 @@ def main():
 
     # Preheat is timed per rank, so it must not contain collectives (ranks would run different
     # numbers of them and deadlock): plain local frames, no gather / all-reduce.
+    # It runs for at least --preheat-seconds and then until two consecutive blocks of frames take the same
+    # time within 2 % (the clocks have settled), at most three times as long.
     t_heat = time.perf_counter()
-    while time.perf_counter() - t_heat < args.preheat_seconds:
-        D.run_frame_loop(lambda slot: mgr.queue_frame(rdr, gnm, gprof, tc), 4, depth=args.depth)
+    last = None
+    while args.preheat_seconds > 0:
+        tb = time.perf_counter()
+        D.run_frame_loop(lambda slot: mgr.queue_frame(rdr, gnm, gprof, tc), 16, depth=args.depth)
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        block = now - tb
+        settled = last is not None and abs(block - last) <= 0.02 * last
+        last = block
+        if (now - t_heat >= args.preheat_seconds and settled) or now - t_heat >= 3.0 * args.preheat_seconds:
+            break
     fence()
     run(args.warmup)
     fence()
