@@ -26,6 +26,17 @@ __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restri
     __hip_atomic_fetch_add(o + 3, df, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum of the packed values of the lanes in `grp`, spilled to the float accumulator by the group's first lane
+__device__ __attribute__((noinline)) void hot_group(u64 v, unsigned long long grp, uint32_t gi, float *__restrict__ out4)
+{
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, sh), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), sh);
+        v += ((u64)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(grp)) spill_cell(v, gi, out4);
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_b(uint32_t v, uint32_t) {      // DPP scan, see iter.hip
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
@@ -174,16 +185,39 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #else
             for (int k = 0; k < ILP; ++k) val[k] = pal[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
 #endif
+            // A cell that takes most of the samples (a point attractor takes all of them) would receive
+            // thousands of adds between the moment its count passes the drain threshold and the moment
+            // the drain executes — enough to carry out of the 10-bit count.  When at least 48 lanes of the
+            // step's first 64 records share one cell, the step is examined record set by record set:
+            // the lanes that share the first lane's cell are summed in registers (at most 64 hits: no
+            // field overflows) and go straight to the float accumulator (hot_group, out of line; the
+            // test on the first set costs four instructions per 256 records).
+            {
+                const uint32_t o0 = rec[0] >> 8;
+                if (__builtin_expect(__popcll(__ballot(live[0] && o0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)o0))) >= 48, 0)) {
+#pragma unroll
+                    for (int k = 0; k < ILP; ++k) {
+                        const uint32_t off = rec[k] >> 8;
+                        const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                        const bool mine = live[k] && off == off0;
+                        const unsigned long long grp = __ballot(mine);
+                        if (__popcll(grp) >= 16) {
+                            hot_group(mine ? val[k] : 0ull, grp, (ty * FL_TILE_H + (off0 >> TWL)) * astride + tx * TW + (off0 & (TW - 1u)), out4);
+                            live[k] = live[k] && !mine;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
-                if (!live[k]) continue;
                 const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
+                if (!live[k]) continue;
 #ifdef ACC_X_NOATOM
                 const u64 old = tile[off ^ 1u]; if (val[k] == 0x1234567ull) tile[off] = old;
 #else
                 const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-                if ((uint32_t)(old >> 32) >= (256u << 23)) {
+                if ((uint32_t)(old >> 32) >= (128u << 23)) {                     // 256 hits: drained early, three quarters of the count's range left for adds in flight
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
                         const uint32_t px = tx * TW + (off & (TW - 1u)), py = ty * FL_TILE_H + (off >> TWL);

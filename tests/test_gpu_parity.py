@@ -335,6 +335,45 @@ def hot_flame():
     return gnm, dict(prof, width=512, height=512)
 
 
+def point_flame(share):
+    """The transcendental-free flame plus an xform that maps everything onto ONE point: that pixel
+    takes about `share` of all samples (share 1: the point xform alone)."""
+    gnm, prof = linear_flame()
+    point = {'weight': 1.0, 'color': 0.8, 'color_speed': 0.5, 'pre_affine': configs._affine(0.0, 0.0, 0.21, -0.13),
+             'variations': {'linear': {'weight': 1.0}}}
+    if share >= 1.0:
+        gnm['xforms'] = {'0': point}
+    else:
+        total = sum(x['weight'] for x in gnm['xforms'].values())
+        gnm['xforms']['3'] = dict(point, weight=total * share / (1.0 - share))
+    return gnm, dict(prof, width=512, height=512)
+
+
+@pytest.mark.parametrize('share', [1.0, 0.9, 0.6, 0.3])
+def test_binned_point_attractor_keeps_every_sample(mgr_prod, share):
+    """A pixel that receives most of the samples: thousands of adds reach its LDS cell between the
+    moment the count passes the drain threshold and the drain, enough to carry out of the 10-bit
+    count (before the step-level test in k_accum_tiles sent such groups straight to the float
+    accumulator, this flame lost 6-33 % of its density).  75 M samples in two launches: the float32
+    accumulators are past 2^24 and no longer count exactly on either side, so the density is held to
+    the number of accepted samples within float rounding instead of bit for bit."""
+    gnm, prof = point_flame(share)
+    res, ref_state, dev_state, dim, _ = run_device_model(mgr_prod, gnm, prof, nrounds=96, fuse=16, launches=2, mode=1)
+    accepted = 0
+    for k, r in enumerate(res):
+        assert np.array_equal(r['ctr_dev'][:2], r['ctr_ref'][:2]), (k, r['ctr_dev'], r['ctr_ref'])
+        accepted += int(r['ctr_dev'][0])
+        dd, dr = r['front_dev'][:, 3].astype(np.float64), r['front_ref'][:, 3].astype(np.float64)
+        assert abs(dd.sum() - accepted) <= 2e-3 * accepted, (share, k, dd.sum(), accepted)
+        assert abs(dr.sum() - accepted) <= 2e-3 * accepted, (share, k, dr.sum(), accepted)
+        hot = int(np.argmax(dr))
+        assert dr[hot] >= 0.25 * share * accepted and abs(dd[hot] - dr[hot]) <= 2e-3 * dr[hot], (share, k, dd[hot], dr[hot])
+        cold = dr < 2 ** 22                                   # everywhere else the counts are exact
+        assert np.array_equal(dd[cold], dr[cold]), (share, k, int((dd[cold] != dr[cold]).sum()))
+        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=1e-2, atol=1e-3)   # float32 sums of 10^7 terms, grouped differently
+    assert np.array_equal(dev_state[0], ref_state[0])
+
+
 def test_iter_hot_pixels_and_spill(mgr):
     """
     Hot-pixel machinery: cells that fill up are drained by the overflow path, the flush sets
@@ -416,7 +455,7 @@ def test_larger_workgroups_bit_exact(nw, nslots, layout, monkeypatch, built):
     for k, r in enumerate(res):
         assert np.array_equal(r['ctr_dev'][:2], r['ctr_ref'][:2]), (k, r['ctr_dev'], r['ctr_ref'])
         assert int((r['front_dev'][:, 3] != r['front_ref'][:, 3]).sum()) == 0
-        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=2e-6, atol=1e-4)
+        np.testing.assert_allclose(r['front_dev'][:, :3], r['front_ref'][:, :3], rtol=1e-5, atol=1e-4)   # float atomics: order varies
     assert np.array_equal(dev_state[0], ref_state[0])
     m.fb.free()
 
