@@ -248,8 +248,9 @@ class RenderManager(object):
     # (render.py:215: one whole round block, a by-product of its launch granularity); flam3 uses 15.
     # The CPU device model shows the start-up transient is gone after 16 iterations for the
     # BASELINE flames even when only 8 write rounds follow (DESIGN.md §4.1 'fuse'); 64 keeps a 4x
-    # margin.  Set to 256 for the reference's literal schedule.
-    fuse = 64
+    # margin.  Set to 256 (or FLAME_FUSE=256) for the reference's literal schedule — a genome made of ONE
+    # slowly contracting xform can still show its start-up transient at 64 (DESIGN.md §5 'Fuse').
+    fuse = int(os.environ.get('FLAME_FUSE', 64))
 
     def __init__(self, device=None, nslots=None, host_seed=None, stream=None):
         if device is None:
