@@ -148,7 +148,11 @@ class X264Output(Output):
             self.framesize = tuple(buf.shape[:2])
             self._color = self._start(self.framesize, False)
             if self.alpha:
-                self._alpha = self._start(self.framesize, True)
+                try:
+                    self._alpha = self._start(self.framesize, True)
+                except IOError:                     # do not leave the colour encoder running without its twin
+                    self._color.proc.kill(); self._color = None
+                    raise
                 self._neutral = np.full(self.framesize[0] * self.framesize[1] // 2, 32767, dtype='u2')   # both chroma planes
         self._color.write(buf[:, :, :3])
         if self.alpha:

@@ -12,7 +12,6 @@ when complete (``.tmp`` + rename, distribute.py:210-212).
 """
 import os
 import sys
-import time
 import traceback
 
 MAX_RETRIES = 3            # distribute.py:218
@@ -79,7 +78,6 @@ def run_jobs(jobs, render_job, log=None):
                 lost.extend(n for n, _, _ in todo)
                 log('giving up after %d consecutive failures; %d jobs left undone' % (streak, len(todo)))
                 break
-            time.sleep(0.0)
             continue
         streak = 0
         done.append(name)
