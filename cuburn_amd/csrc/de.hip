@@ -193,14 +193,17 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
     const float ccx = cen.x * cfix, ccy = cen.y * cfix, ccz = cen.z * cfix;
     const bool cen_live = cen.w > 0.0f;
-    // cs*|n_q - c|^2 = S_q + n_q . C' + cs*|c|^2; the last term is the same for every tap of this
-    // centre and stays outside the loop (see the end).  A dead tap or a dead centre makes the colour
-    // difference 0.5: select cs/2 (minus the factored term).
+    // cs*|n_q - c|^2 = S_q + n_q . C' + cs*|c|^2.  The last term is the same for every tap of this
+    // centre, but it cannot be factored out of the loop: for a narrow colour kernel (cstd < ~0.03) or
+    // colours above 1 the partial exponent S_q + n_q . C' reaches +150 and 2^(cs*|c|^2) underflows —
+    // the sums overflow to inf and come back as NaN / 0 (found by tools/soak_filters.py; the full
+    // exponent is never positive).  It is added to S_q: one instruction per tap.  A dead tap or a
+    // dead centre makes the colour difference 0.5: select cs/2.
     const float m2 = -2.0f * cs2;
     float Cx = ccx * m2, Cy = ccy * m2, Cz = ccz * m2;
-    const float biasp = cen_live ? cs2 * fmaf(ccz, ccz, fmaf(ccy, ccy, ccx * ccx)) : 0.0f;
+    float biasp = cen_live ? cs2 * fmaf(ccz, ccz, fmaf(ccy, ccy, ccx * ccx)) : 0.0f;
     float thr = cen_live ? 0.0f : __builtin_inff();           // tap live <=> w_q > thr
-    float Kp = 0.5f * cs2 - biasp;
+    float Kp = 0.5f * cs2;
     float cds = bB[TOFFB(0)].x;                               // |ds| * w_c^dpow
     float wprev = G::HOIST ? 0.0f : bA[TOFF(-16)].w;
     const float4 p0 = bA[TOFF(-15)];
@@ -222,16 +225,16 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
         if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
         constexpr int inflight = g + 1 < 16 ? de_tap_reads<P>(-15 + (g + 1) * 2) + de_tap_reads<P>(-14 + (g + 1) * 2) : 0;
         DeTap (&T)[2] = L[g & 1];
-        asm volatile("s_waitcnt lgkmcnt(%19)"
+        asm volatile("s_waitcnt lgkmcnt(%20)"
                      : "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b),
                        "+v"(aA), "+v"(aB), "+v"(ox), "+v"(oy), "+v"(oz), "+v"(ow), "+v"(wsum),
-                       "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(thr), "+v"(Kp), "+v"(cds)
+                       "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(thr), "+v"(Kp), "+v"(cds), "+v"(biasp)
                      : "n"(inflight));
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int r = -15 + g * 2 + k;
             if (r <= 15) {
-                float t = fmaf(pix.x, Cx, fmaf(pix.y, Cy, fmaf(pix.z, Cz, T[k].b.y)));
+                float t = fmaf(pix.x, Cx, fmaf(pix.y, Cy, fmaf(pix.z, Cz, T[k].b.y + biasp)));
                 t = pix.w > thr ? t : Kp;
                 float e = t - fabsf(cds - T[k].b.x);
                 if (r != 0) {
@@ -256,13 +259,10 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     }(std::make_integer_sequence<int, 16>{});
 #undef TOFF
 #undef TOFFB
-    // undo the factored 2^(cs*|c|^2): out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is
-    // their ratio (the 1/weightsum of the reference cancels, and so does the factor), the density
-    // is out.w / (weightsum + 1e-10)
-    const float Bf = fexp2(biasp);
-    const float tw = ow * Bf;
-    const float wn = tw * frcp(fmaf(wsum, Bf, 1e-10f));
-    const float rn = tw >= 1.17549435e-38f ? frcp(ow) : 0.0f;   // v_rcp_f32 of a denormal is +inf
+    // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the 1/weightsum of the
+    // reference cancels), the density is out.w / (weightsum + 1e-10)
+    const float wn = ow * frcp(wsum + 1e-10f);
+    const float rn = ow >= 1.17549435e-38f ? frcp(ow) : 0.0f;   // v_rcp_f32 of a denormal is +inf
     res = make_float4(ox * rn, oy * rn, oz * rn, wn);
 }
 

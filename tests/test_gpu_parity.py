@@ -605,6 +605,25 @@ def test_filter_bilateral_chain(mgr):
     assert_close(dev, ref, 2e-3, 2e-4, 'bilateral chain')
 
 
+@pytest.mark.parametrize('cstd', [0.02, 0.006])
+def test_filter_bilateral_narrow_colour_kernel(mgr, cstd):
+    """A colour standard deviation well below the default 0.05 (the profile's `color_std` is a free
+    spline): cs = -17 / -57 per unit of squared colour distance, and colours above 1 after yuv -> rgb.
+    The one-kernel-per-direction form once factored 2^(cs*|c|^2) out of the tap loop: the partial
+    exponents overflowed and whole regions came back as 0 / 1 (tools/soak_filters.py)."""
+    dim = mgr.fb.calc_dim(FW, FH); d = O.calc_dim(FW, FH)
+    buf = O.yuv_to_rgb(d, synth_accum(dim, seed=5))
+    n = buf[:, :3] / np.maximum(buf[:, 3:4], 1e-20)
+    assert (n[buf[:, 3] > 0] ** 2).sum(1).max() > 2.0           # |c|^2 > 2: cs * |c|^2 beyond the exp2 range at cstd 0.006
+    vals = [6.0 * FW / 1920., cstd, 1.5, 0.8, 4.0]
+    dev = run_filter(mgr, 'bilateral', dim, buf, vals)
+    ref = O.bilateral_chain(d, buf, *vals)
+    assert np.isfinite(dev).all()
+    err = np.abs(dev - ref)
+    tol = 2e-4 + 2e-3 * np.abs(ref)
+    assert (err > tol).mean() < 2e-4, ((err > tol).mean(), err.max())
+
+
 def sparse_accum(dim, seed=3):
     """A few-samples-per-pixel buffer: isolated single hits, empty gaps, black and saturated colours
     (the regime where the DE weights underflow to denormals)."""
