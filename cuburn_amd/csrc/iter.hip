@@ -292,16 +292,19 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
         const int k_cur = k_next;
         const float *__restrict__ xf_cur = xf_next;
-        const XfHead hcur = hnext;
         sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
         k_next = choose(sel_next);
         xf_next = P + xf_off + k_next * xf_stride;
-        hnext = load_head(xf_next);                                         // arrives during this round
+        // The next record is requested AFTER this round's xform has used the current one: it lands in the
+        // same scalar registers (no second set and no nine register copies every round — the scalar unit is
+        // on this kernel's critical path) and still has the swap, the barrier and the rest of the round to
+        // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
-        if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hcur, xf_cur, x, y, color, rctx);
+        if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
 #endif
-        apply_xf(hcur, xf_cur, var_stride, x, y, color, rctx);
+        apply_xf(hnext, xf_cur, var_stride, x, y, color, rctx);
+        hnext = load_head(xf_next);
         (void)k_cur;
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
@@ -502,7 +505,7 @@ extern "C" __global__ void __launch_bounds__(FL_SPEC_NW * 64) k_iter_spec(FL_ITE
 }
 #else
 template <int NW, bool COUNT, int ACC>
-__global__ void __launch_bounds__(NW * 64) k_iter(FL_ITER_ARGS)
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 6 : NW == 8 ? 3 : 1) k_iter(FL_ITER_ARGS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     iter_body<NW, COUNT, ACC, false>(smem, FL_ITER_PASS);
