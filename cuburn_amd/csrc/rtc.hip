@@ -116,9 +116,7 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #ifdef FL_CNT_SETS_BIG
                           "-DFL_CNT_SETS_BIG=" FL_STR(FL_CNT_SETS_BIG),
 #endif
-#ifdef FL_ITER_NO_SLP
                           "-fno-slp-vectorize",
-#endif
     };
     const hiprtcResult rc = a.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
     if (rc != HIPRTC_SUCCESS) {
