@@ -31,6 +31,9 @@
 #ifndef FL_SCAN_SERIAL_MAX
 #define FL_SCAN_SERIAL_MAX 8u
 #endif
+#ifndef FL_SPLIT_MAX_XF
+#define FL_SPLIT_MAX_XF 9         /* per-genome kernels with more xforms keep a single copy of the walk */
+#endif
 #ifndef FL_CNT_SETS
 #define FL_CNT_SETS 3          /* sets of tile counters per 4-wave workgroup (LDS: an array of tiles + 1 words each) */
 #endif
@@ -233,7 +236,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
     if (!BINNED) for (int i = tid; i < FL_PAL_W; i += NT) palrow[i] = palette[prow * FL_PAL_W + i];
     if (BINNED) for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;
-    uint32_t staged = 0, batch_in_slot = 0;
+    uint32_t batch_in_slot = 0;
 
     const size_t wi = (size_t)slot * NT + tid;
     mwc_t rctx = {rng[wi].mul, rng[wi].state, rng[wi].carry};
@@ -287,7 +290,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     const float *__restrict__ xf_next = P + xf_off + k_next * xf_stride;
     XfHead hnext = load_head(xf_next);
 
-    for (uint32_t rd = 0; rd < nrounds; ++rd) {
+    // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
+    uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
+    auto advance = [&]() __attribute__((always_inline)) {
         if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
 
         const int k_cur = k_next;
@@ -309,13 +314,34 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
-            const uint32_t par = rd & 1u, dst = rot0;
+            const uint32_t dst = rot0;
             rot0 = rot1; rot1 = rot2; rot2 = dst;           // the three-phase destination cycle
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+            par ^= 1u;
         }
-        if (rd < fuse) continue;                                            // iter.py:298-300
+    };
+    // The loop is split by what a round does besides walking — nothing (the fuse rounds, iter.py:298-300),
+    // or plotting, in batches of bg.rounds rounds that end with the tile sort — so that a round's loop
+    // bookkeeping is ONE counter: the scalar unit is on this kernel's critical path.
+    const uint32_t nfuse = min(fuse, nrounds);
+#ifdef FL_RTC
+    constexpr bool SPLIT_FUSE = !SPEC || FL_SPEC_NXF <= FL_SPLIT_MAX_XF;
+#else
+    constexpr bool SPLIT_FUSE = true;
+#endif
+    // (a kernel with many heavy xforms keeps ONE copy of the walk: there the fuse rounds run through the
+    // plotting loop with the plot skipped — a second copy of twelve inlined xforms cost cfg5 7 %)
+    if (SPLIT_FUSE) for (uint32_t rd = 0; rd < nfuse; ++rd) advance();
+    uint32_t fuse_left = SPLIT_FUSE ? 0u : nfuse;
+    for (uint32_t rd = SPLIT_FUSE ? nfuse : 0u; rd < nrounds;) {
+    const uint32_t blen = fuse_left ? fuse_left : BINNED ? min(bg.rounds, nrounds - rd) : nrounds - rd;
+    const bool plotting = fuse_left == 0u;
+    fuse_left = 0u;
+    for (uint32_t staged = 0; staged < blen; ++staged) {
+        advance();
+        if (!SPLIT_FUSE && !plotting) continue;
 
         float fx = x, fy = y, fc = color;
 #ifdef FL_RTC
@@ -369,7 +395,16 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             if (WIDE) skey[staged * NT + tid] = (uint16_t)bin;
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(my_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (++staged == bg.rounds || rd + 1 == nrounds) {
+        } else {
+            // measurement mode: everything but the accumulate (ceiling of the walk itself)
+            pend_old += ok ? val + gi : 0ull;
+        }
+        if (COUNT) n_acc += ok;
+    }
+    rd += blen;
+    if (BINNED && plotting) {
+            {
+                const uint32_t staged = blen;
                 // slot-major: the batches of a slot are neighbours in the log and the directory, so a range
                 // of batch ids covers few slots, i.e. few palette rows (binned.hip stages them in LDS)
                 const uint32_t batch_id = slot * (bg.nbatch_total / gridDim.x) + batch_in_slot;
@@ -464,14 +499,10 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 const uint4 *src = reinterpret_cast<const uint4 *>(stage);
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
                 for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
-                staged = 0; ++batch_in_slot;
+                ++batch_in_slot;
                 __syncthreads();
             }
-        } else {
-            // measurement mode: everything but the accumulate (ceiling of the walk itself)
-            pend_old += ok ? val + gi : 0ull;
-        }
-        if (COUNT) n_acc += ok;
+    }
     }
 
     if (ACC == 0) drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
