@@ -18,12 +18,13 @@ preheat, W warm-up steps, K timed steps (barrier + synchronize on both sides, ma
 then the kernel-level section on a one-lane context.
 
 Prints ONE JSON line on rank 0:
-  value     = write-enabled chaos-game samples per second, whole job (Msamples/s), fuse 64
-  config.fuse_reference = the same loop with the reference's fuse of 256 (cuburn/render.py:215)
+  value     = write-enabled chaos-game samples per second, whole job (Msamples/s), at the default fuse —
+              the reference's 256 write-disabled rounds per walker and frame (cuburn/render.py:215)
+  config.fuse_short = the same loop with a fuse of 64 (enough for the BASELINE flames; not the default)
   roofline  = the iterate CHAIN (k_iter + k_accum_tiles + k_flush — the kernels that together perform
               the 8-byte read-modify-write per sample that SURVEY.md §8d's 16 B/sample stand for):
               16 B x samples / HIP-event time of those kernels, vs the 8 TB/s HBM peak.  `traffic` =
-              HBM bytes of the chain per frame from the TCC counters (profiles/r02_pmc_traffic.json:
+              HBM bytes of the chain per frame from the TCC counters (profiles/r0N_pmc_traffic.json, newest round:
               rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per
               MI355X_MICROARCH.md §HBM).  `k_iter` carries that kernel's own launch time and its
               MEASURED bytes (it writes 4-byte log records, not the packed cells).
@@ -126,9 +127,59 @@ def copy_bandwidth(torch, device):
     return 2 * n * 16 / (ms * 1e-3) / 1e9
 
 
+def launch_ranks(ngpus, argv):
+    """
+    `python bench.py --gpus N` with N > 1 outside a launcher: start N ranks ourselves (one process
+    per GPU, as the reference's dispatcher starts its own workers, distribute.py:131-186) as a CHILD
+    `python -m torch.distributed.run`, relay its output and return its exit code.  This process has
+    not touched the GPU (torch is not even imported) and never execs.
+    """
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                       # rank 0's JSON line (and anything else a rank prints)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the multi-rank control flow without any rendering (CPU test of the launcher): process
+    group, world-size check, barrier, max-over-ranks reduction, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, 'launched with %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus)
+        tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.barrier()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        assert int(tt.item()) == world
+        n = dist.get_world_size()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': n, 'steps': args.steps, 'warmup': args.warmup, 'value': None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--dry-run', action='store_true', help='control flow only: no rendering, no GPU (launcher test)')
+    ap.add_argument('--min-timed-frames', type=int, default=300,
+                    help='the timed region repeats the K steps until it holds at least this many frames '
+                         '(K frames of 1.7 ms are a 30 ms window); per-step numbers are reported')
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='cfg2')
@@ -147,9 +198,15 @@ def main():
     ap.add_argument('--gather-block', type=int, default=4, help='frames per gather collective')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:          # not under a launcher: start the ranks
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started %d rank(s)' % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     from cuburn_amd import configs
     gnm, prof = configs.CONFIGS[args.config]()
@@ -172,6 +229,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, 'process group of %d ranks for --gpus %d' % (dist.get_world_size(), args.gpus)
     coll_dev = 'cuda' if world == 1 or dist.get_backend() == 'nccl' else 'cpu'
     torch.cuda.set_device(local)
 
@@ -223,24 +281,31 @@ def main():
         last = block
         if (now - t_heat >= args.preheat_seconds and settled) or now - t_heat >= 3.0 * args.preheat_seconds:
             break
+    # The timed region holds `reps` back-to-back repetitions of the K steps (K frames of 1.7 ms are a
+    # 30 ms window): barrier + synchronize on both sides, per-step numbers reported.
+    reps = max(1, -(-args.min_timed_frames // max(args.steps, 1)))
     fence()
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    run(args.steps)
+    for _ in range(reps):
+        run(args.steps)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = (time.perf_counter() - t0) / reps
     samples_per_frame = mgr.last_nsamples
 
-    # the same loop at the reference's fuse (256 write-disabled rounds at the start of every frame)
+    # the same loop at the other fuse length: the default is the reference's 256 write-disabled rounds
+    # at the start of every frame (cuburn/render.py:215); 64 is what the BASELINE flames need
     fuse_main = mgr.fuse
-    mgr.fuse = 256
+    fuse_other = 64 if fuse_main != 64 else 256
+    mgr.fuse = fuse_other
     run(min(args.warmup, 2))
     fence()
     t1 = time.perf_counter()
-    run(args.steps)
+    for _ in range(reps):
+        run(args.steps)
     fence()
-    elapsed_ref = time.perf_counter() - t1
+    elapsed_ref = (time.perf_counter() - t1) / reps
     mgr.fuse = fuse_main
 
     # Kernel-level numbers are taken un-overlapped: a second context with ONE stream lane renders
@@ -262,7 +327,7 @@ def main():
         t['samples'] = kmgr.last_nsamples * ksteps
         return t
     acc = kernel_times(fuse_main)
-    acc_ref = kernel_times(256)
+    acc_ref = kernel_times(fuse_other)
     # the native context reads the switches when it is created, which happens lazily on the first frame
     del os.environ['FLAME_LANES']
     del os.environ['FLAME_NO_INTRA_OVERLAP']
@@ -284,18 +349,24 @@ def main():
         chain_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
         chain = 16.0 * acc['samples'] / chain_s / 1e9 if chain_s > 0 else 0.0
         chain_ref_s = (acc_ref['iter_ms'] + acc_ref['flush_ms']) * 1e-3
-        traffic, iter_bytes = None, None
+        traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
         try:        # measured offline with tools/pmc_traffic.sh on this workload (KB units, reads x2)
-            pmc = json.load(open(os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')))
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r0*_pmc_traffic.json')))[-1]
+            pmc = json.load(open(pmc_file))
             def kb(sub):
-                ks = [k for k in pmc if sub in k]
-                c = pmc[ks[0]]
-                return (2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024
+                tot = 0.0
+                for k in pmc:
+                    if sub in k:
+                        c = pmc[k]
+                        tot += (2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024
+                return tot
             if args.config == 'cfg2' and args.accum == 'binned':
                 iter_bytes = int(kb('k_iter'))
                 traffic = int(iter_bytes + kb('k_accum_tiles') + kb('k_flush'))
+                de_traffic = int(kb('k_de_')) or None
         except Exception:
-            traffic, iter_bytes = None, None
+            traffic, iter_bytes, de_traffic = None, None, None
         launches = max(acc['launches'], 1)
         iter_launch_s = acc['iter_ms'] * 1e-3 / launches
         de_s = (acc['de_ms'] + acc['de_finish_ms']) * 1e-3 / ksteps
@@ -304,7 +375,7 @@ def main():
             'metric': 'Msamples/s into 1920x1080 histogram + DE-filter GB/s vs HBM roofline',
             'value': round(job_samples_per_step * args.steps / elapsed / 1e6, 2),
             'unit': 'Msamples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': dist.get_world_size() if dist is not None else 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak' if args.shard == 'frames' else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -313,20 +384,22 @@ def main():
                        else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
                             % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
                        'walker_waves': mgr.fb.nw,
-                       'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': 2,
+                       'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round((acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps, 4),
+                                        'note': 'the big kernels do not overlap usefully (DESIGN 4.1): the second lane hides copies, clears and launch gaps only'},
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
                        'frames_queued_ahead': args.depth, 'frames_per_gpu': args.steps,
                        'per_genome_kernel': os.environ.get('FLAME_RTC', '1') != '0',
-                       'fuse_reference': {'fuse': 256, 'value': round(job_samples_per_step * args.steps / elapsed_ref / 1e6, 2),
-                                          'ms_per_step': round(elapsed_ref / args.steps * 1e3, 3),
-                                          'iter_chain_ms_per_frame': round(chain_ref_s / ksteps * 1e3, 4),
-                                          'note': 'the reference spends one 256-iteration round block per frame on un-plotted iterations '
-                                                  '(render.py:215); value counts write-enabled samples only'},
+                       'fuse_short': {'fuse': fuse_other, 'value': round(job_samples_per_step * args.steps / elapsed_ref / 1e6, 2),
+                                      'ms_per_step': round(elapsed_ref / args.steps * 1e3, 3),
+                                      'iter_chain_ms_per_frame': round(chain_ref_s / ksteps * 1e3, 4),
+                                      'note': 'the default fuse is the reference\'s: one 256-iteration round block per walker and frame '
+                                              'of un-plotted iterations (render.py:215); value counts write-enabled samples only'},
+                       'timed_frames': reps * args.steps,
                        'parallelism': ('frame-sharded x%d, RCCL gather of device frames, %d frames per collective' % (world, args.gather_block)
                                        if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators' % world)},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter + k_accum_tiles + k_flush (iterate chain: the 8-byte packed-cell RMW per sample)',
                          'achieved': round(chain, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(chain / HBM_PEAK_GBS, 5),
-                         'traffic': traffic,
+                         'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file else None,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
                          'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'VALU / SALU issue (not bandwidth)',
@@ -339,6 +412,7 @@ def main():
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
+                          'traffic': de_traffic,
                           'bound': 'VALU issue (SQ counters in profiles/): 512 B/px is the algorithmic byte count of the reference pass structure'},
             'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),
                                     'filters': round(acc['filter_ms'] / ksteps, 4), 'note': 'un-overlapped (single stream lane)'},

@@ -78,8 +78,21 @@ def render(args, prof):
     took = [0]
 
     def render_job(name, times):
+        try:
+            render_job_(name, times)
+        except Exception:
+            # a failed job leaves nothing behind: frames still queued are waited for, the encoder is killed
+            try:
+                from . import _lib
+                _lib.load().fl_ctx_sync(rmgr.fb.ctx)
+            except Exception:
+                pass
+            rdr.out.abort()
+            raise
+
+    def render_job_(name, times):
         times = list(times)
-        rdr.out = output.get_output_for_profile(gprof)       # a fresh encoder per file (a failed job leaves none behind)
+        rdr.out = output.get_output_for_profile(gprof)       # a fresh encoder per file
         for idx, (evt, frame) in _one_ahead(lambda t: rmgr.queue_frame(rdr, gnm, gprof, t), times):
             while took[0] > 2000 and not evt.query():        # long frames: poll, keep the interpreter responsive
                 time.sleep(0.2)

@@ -924,19 +924,22 @@ int fl_sort_u32(fl_ctx *c, uint64_t dst_dev, uint64_t src_dev, uint32_t n, uint3
     if (n == 0) { if (nvalid) *nvalid = 0; return FL_OK; }
     size_t chunk_words = 0;
     const size_t hist_words = sort_scratch_words(n, nbits, &chunk_words), need = hist_words + chunk_words;
+    // Every pass runs on lane 0's stream whatever lane the frame loop is on: consecutive passes of a
+    // multi-pass sort stay ordered across frame boundaries, and the scratch has ONE user stream.
+    hipStream_t sst = c->lanes[0].stream;
     if (need > c->sort_words) {
-        HIPCHK(hipStreamSynchronize(L(c).stream));
+        sync_all(c);                                        // nothing may still be using the old scratch
         hipFree(c->d_sort); c->d_sort = nullptr; c->sort_words = 0;
         HIPCHK(hipMalloc(&c->d_sort, need * 4));
         c->sort_words = need;
     }
     uint32_t *chunk_tot = c->d_sort + hist_words, *total_dev = chunk_tot + (chunk_words - 1);
-    launch_sort_pass(L(c).stream, (uint32_t *)(uintptr_t)dst_dev, (const uint32_t *)(uintptr_t)src_dev, n, lo_bit, nbits,
+    launch_sort_pass(sst, (uint32_t *)(uintptr_t)dst_dev, (const uint32_t *)(uintptr_t)src_dev, n, lo_bit, nbits,
                      ignore_max, c->d_sort, chunk_tot, total_dev);
     HIPCHK(hipGetLastError());
     if (nvalid) {                                           // the reference leaves this count on the device (sort.py:449-452)
-        HIPCHK(hipMemcpyAsync(nvalid, total_dev, 4, hipMemcpyDeviceToHost, L(c).stream));
-        HIPCHK(hipStreamSynchronize(L(c).stream));
+        HIPCHK(hipMemcpyAsync(nvalid, total_dev, 4, hipMemcpyDeviceToHost, sst));
+        HIPCHK(hipStreamSynchronize(sst));
     }
     return FL_OK;
 }

@@ -104,8 +104,18 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
     const char *hdr_src[] = {rtc_src_variations, rtc_src_device, rtc_src_abi, header.c_str()};
     const char *hdr_name[] = {"variations.h", "flame_device.h", "flame_hip.h", "flame_spec.h"};
     if (a.create(&prog, rtc_src_iter, "iter.hip", 4, hdr_src, hdr_name) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return -1; }
-    // same code generation options as the ahead-of-time build of iter.hip (csrc/Makefile)
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-DFL_RTC=1",
+    // same code generation options as the ahead-of-time build of iter.hip (csrc/Makefile); the target is the
+    // current device's own architecture string (fl_ctx_create has refused anything that is not gfx950)
+    std::string arch_opt = "--offload-arch=gfx950";
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+            std::string name(prop.gcnArchName);
+            arch_opt = "--offload-arch=" + name.substr(0, name.find(':'));
+        } else (void)hipGetLastError();
+    }
+    const char *opts[] = {arch_opt.c_str(), "-O3", "-std=c++20", "-ffp-contract=off", "-DFL_RTC=1",
                           "-mllvm", "-structurizecfg-skip-uniform-regions=true",
 #ifdef FL_SCAN_SERIAL_MAX
                           "-DFL_SCAN_SERIAL_MAX=" FL_STR(FL_SCAN_SERIAL_MAX),
@@ -158,10 +168,16 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int ac
     if (hipModuleGetFunction(&e.fn, e.mod, "k_iter_spec") != hipSuccess) {
         (void)hipGetLastError(); (void)hipModuleUnload(e.mod); *err = "k_iter_spec not found in the compiled module"; return -1;
     }
-    if (g_cache.size() >= kMaxModules) {            // simple bound: drop everything (kernels may still be queued: sync first)
+    if (g_cache.size() >= kMaxModules) {
+        // simple bound: drop THIS device's modules (the current device is `device`: its queued kernels are
+        // waited for first); modules of other devices held by the process stay loaded — their kernels may
+        // still be queued and this thread cannot wait for them from here
         (void)hipDeviceSynchronize();
-        for (auto &kv : g_cache) (void)hipModuleUnload(kv.second.mod);
-        g_cache.clear();
+        const std::string prefix = std::to_string(device) + "|";
+        for (auto kv = g_cache.begin(); kv != g_cache.end();) {
+            if (kv->first.compare(0, prefix.size(), prefix) == 0) { (void)hipModuleUnload(kv->second.mod); kv = g_cache.erase(kv); }
+            else ++kv;
+        }
         ++g_epoch;
     }
     g_cache[key] = e;

@@ -89,6 +89,12 @@ class FrameGather(object):
     blocks alternate, so a block is only waited for when it is about to be re-used, 2 x block frames
     later.  All ranks must submit the same number of frames.  ``sink(rank, index, frame)`` is
     called on ``dst`` for every received frame (index = the rank's own frame counter).
+
+    ``slot()`` re-enters a block only when every frame it handed out from it last time has been
+    submitted (and therefore its gather launched), i.e. with at most ``block`` frames handed out and not
+    yet submitted; otherwise the tensor would still be rendered into, or not yet gathered, and ``slot()``
+    raises.  ``run_frame_loop`` has ``depth`` frames outstanding when it asks for a slot, so it needs
+    ``depth <= block`` (checked there).
     """
 
     def __init__(self, shape, dtype, device, block=4, dst=0, sink=None):
@@ -122,6 +128,12 @@ class FrameGather(object):
         """Tensor the next frame must be written to (valid until that frame is submitted)."""
         b = (self.n_alloc // self.block) % 2
         if self.n_alloc % self.block == 0:
+            # the block was last handed out for frames [n_alloc - 2 * block, n_alloc - block): all of them
+            # must have been submitted, or one is still being rendered into the tensor about to be re-used
+            if self.n_alloc - self.n_done > self.block:
+                raise RuntimeError('FrameGather: %d frames handed out and not submitted; block %d of %d frames would be '
+                                   're-used while one of its frames is still outstanding (queue depth must stay below '
+                                   'the block size)' % (self.n_alloc - self.n_done, b, self.block))
             self._harvest(b)                 # the gather that last used this block has to be done
         t = self.blocks[b][self.n_alloc % self.block]
         self.n_alloc += 1
@@ -161,6 +173,9 @@ def run_frame_loop(queue_frame, nframes, depth=2, gather=None, stage=None):
     frame into its slot when frames are not rendered into it directly (CPU collectives).
     Returns the number of frames completed.
     """
+    if gather is not None and depth > gather.block:
+        raise ValueError('run_frame_loop: %d frames queued ahead need gather blocks of at least %d frames (got %d)'
+                         % (depth, depth, gather.block))
     pending = []
 
     def finish(item):

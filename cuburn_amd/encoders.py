@@ -43,6 +43,15 @@ class _EncoderPipe(object):
         except (IOError, OSError) as e:
             raise IOError('%s stopped reading frames: %s\n%s' % (self.what, e, self._log()))
 
+    def abort(self):
+        """Kill the encoder and drop its temporary files (a failed job must leave nothing running)."""
+        for step in (lambda: self.proc.stdin.close(), self.proc.kill, self.proc.wait, self.errf.close,
+                     lambda: self.outf and self.outf.close(), lambda: self.named and self.named.close()):
+            try:
+                step()
+            except Exception:
+                pass
+
     def finish(self):
         """Close stdin, wait for the encoder; returns (media file positioned at 0, log text)."""
         try:
@@ -63,9 +72,20 @@ class _EncoderPipe(object):
         return media, log
 
 
+def _abort_pipes(obj, names):
+    for n in names:
+        pipe = getattr(obj, n, None)
+        if pipe is not None:
+            pipe.abort()
+            setattr(obj, n, None)
+
+
 class _PlanarOutput(Output):
     """Outputs whose device format is planar: ``copy`` shapes per cuburn/output.py:323-338."""
     pix_fmt = 'yuv444p'
+
+    def abort(self):
+        _abort_pipes(self, ('_pipe',))
 
     def shape(self, dim):
         if self.fmt == _lib.OUT['yuv420p10']:
@@ -127,6 +147,9 @@ class X264Output(Output):
         extras += ['--output-csp', 'i420', '--chroma-qp-offset', '24'] if alpha else ['--output-csp', self.csp]
         return _EncoderPipe(self.args + extras, 'x264')
 
+    def abort(self):
+        _abort_pipes(self, ('_color', '_alpha'))
+
     def _flush(self):
         if self._color is None:
             return {}, []
@@ -151,13 +174,17 @@ class X264Output(Output):
                 try:
                     self._alpha = self._start(self.framesize, True)
                 except IOError:                     # do not leave the colour encoder running without its twin
-                    self._color.proc.kill(); self._color = None
+                    self._color.abort(); self._color = None
                     raise
                 self._neutral = np.full(self.framesize[0] * self.framesize[1] // 2, 32767, dtype='u2')   # both chroma planes
-        self._color.write(buf[:, :, :3])
-        if self.alpha:
-            self._alpha.write(buf[:, :, 3])
-            self._alpha.write(self._neutral)
+        try:
+            self._color.write(buf[:, :, :3])
+            if self.alpha:
+                self._alpha.write(buf[:, :, 3])
+                self._alpha.write(self._neutral)
+        except IOError:
+            self.abort()                            # neither encoder survives a failed write
+            raise
         return out
 
 

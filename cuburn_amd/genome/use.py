@@ -1,72 +1,17 @@
 """
-Spec-driven views of genome / profile dicts, and the host spline evaluator.
+Schema-driven read views of genome / profile documents, and the host spline evaluator.
 
-Same surface as cuburn/genome/use.py:6-201: ``Wrapper`` (attribute access with spec
-defaults, sorted container protocol), ``RefWrapper`` (profile scalars multiplied into
-genome splines), ``SplineWrapper`` and ``SplineEval`` (knot normalisation used by the
-packer, host evaluation used for per-frame profile scalars).
+What the render path needs from cuburn/genome/use.py is small: ``gprof.<attr>`` access that falls
+back to the schema's defaults (``gprof.width``, ``gprof.filters.colorclip.gamma(tc)``, ...), profile
+scalars that scale a spline of the genome (``gprof.spp(tc)``), and ``SplineEval`` (knot
+normalisation for the packer, host evaluation of per-frame scalars).  It is built here as ONE view
+class over (document, schema) plus a table of leaf builders, rather than the reference's family of
+wrapper subclasses; the behaviour is pinned by tests/golden/{splines,profile,spec_defaults}.json.
 """
 import numpy as np
+
 from .spectypes import Enum, Spline, Scalar, RefScalar, Map, List
 from .specs import toplevels
-
-
-class Wrapper(object):
-    def __init__(self, val, spec=None, path=(), **params):
-        if spec is None:
-            assert val.get('type') in toplevels, 'Unrecognized dict type'
-            spec = toplevels[val['type']]
-        self._val, self.spec, self.path, self._params = val, spec, path, params
-
-    # -- per-type hooks -------------------------------------------------------------
-    def wrap(self, name, spec, val):
-        path = self.path + (name,)
-        if isinstance(spec, Enum):
-            return self.wrap_enum(path, spec, val)
-        if isinstance(spec, Spline):
-            return self.wrap_spline(path, spec, val)
-        if isinstance(spec, Scalar):
-            return self.wrap_scalar(path, spec, val)
-        if isinstance(spec, RefScalar):
-            return self.wrap_refscalar(path, spec, val)
-        if isinstance(spec, dict):
-            return self.wrap_dict(path, spec, val)
-        if isinstance(spec, Map):
-            return self.wrap_Map(path, spec, val)
-        if isinstance(spec, List):
-            return self.wrap_List(path, spec, val)
-        return val
-
-    def wrap_enum(self, path, spec, val): return val or spec.default
-    def wrap_spline(self, path, spec, val): return val
-    def wrap_scalar(self, path, spec, val): return val if val is not None else spec.default
-    def wrap_refscalar(self, path, spec, val): return val if val is not None else spec.default
-    def wrap_dict(self, path, spec, val): return type(self)(val or {}, spec, path, **self._params)
-    def wrap_Map(self, path, spec, val): return self.wrap_dict(path, spec, val)
-
-    def wrap_List(self, path, spec, val):
-        val = val if val is not None else spec.default
-        return [self.wrap(path[-1], spec.type, v) for v in val]
-
-    def get_spec(self, name):
-        if isinstance(self.spec, Map):
-            return self.spec.type
-        return self.spec[name]
-
-    def __getattr__(self, name):
-        if name.startswith('__'):
-            raise AttributeError(name)
-        return self.wrap(name, self.get_spec(name), self._val.get(name))
-
-    # -- container protocol: only keys present in the document, sorted ----------------
-    def keys(self): return sorted(self._val.keys())
-    def items(self): return [(k, self[k]) for k in self.keys()]
-    def __iter__(self): return iter(self.keys())
-    def __getitem__(self, name): return getattr(self, str(name))
-
-    def __contains__(self, name):
-        self.get_spec(name)
-        return name in self._val
 
 
 class SplineEval(object):
@@ -106,19 +51,18 @@ class SplineEval(object):
             t, v = np.append(t, tail), np.append(v, v[-2] + (tail - t[-2]) * vel[1] * scale)
         return np.stack([t, v])
 
-    def find_knots(self, itime):
+    def _segment(self, itime):
+        """The four knots around ``itime`` with the segment [k1, k2] mapped to [0, 1]:
+        (knot times, knot values, local time, 1 / segment length)."""
         kt, kv = self.knots
-        idx = int(np.searchsorted(kt, itime)) - 2
-        idx = max(0, min(idx, len(kt) - 4))
-        times, vals = kt[idx:idx + 4], kv[idx:idx + 4]
-        t = itime - times[1]
-        times = times - times[1]
-        scale = 1 / times[2]
-        return times * scale, vals, t * scale, scale
+        first = int(np.clip(np.searchsorted(kt, itime) - 2, 0, kt.size - 4))
+        kt, kv = kt[first:first + 4], kv[first:first + 4]
+        inv = 1.0 / (kt[2] - kt[1])
+        return (kt - kt[1]) * inv, kv, (itime - kt[1]) * inv, inv
 
     def __call__(self, itime, deriv=0):
         # As in the reference, host evaluation is always linear-domain (use.py:175).
-        times, vals, t, scale = self.find_knots(itime)
+        times, vals, t, scale = self._segment(itime)
         m1 = (vals[2] - vals[0]) / (1.0 - times[0])
         m2 = (vals[3] - vals[1]) / times[3]
         # Hermite basis rows for (m1, p1, m2, p2) in powers t^3, t^2, t, 1
@@ -128,23 +72,100 @@ class SplineEval(object):
             coef = np.array([0, 3 * coef[0], 2 * coef[1], coef[2]]) * scale
         return float(coef @ np.array([t ** 3, t ** 2, t, 1.0]))
 
-    def __imul__(self, other):
-        self.knots[1] *= other
-        return self
+    def scaled(self, factor):
+        """The same curve with every knot value multiplied by ``factor`` (a new evaluator)."""
+        out = object.__new__(SplineEval)
+        out.knots, out.interp = self.knots * np.array([[1.0], [float(factor)]]), self.interp
+        return out
 
 
-class SplineWrapper(Wrapper):
-    """Genome view whose splines evaluate on the host; needs ``scale`` (= time.duration)."""
-    def wrap_spline(self, path, spec, val):
-        return SplineEval(val if val is not None else spec.default,
-                          self._params['scale'], spec.interp)
+def _or_default(value, node):
+    return node.default if value is None else value
 
 
-class RefWrapper(Wrapper):
-    """Profile view: a RefScalar scales the referenced genome spline (use.py:100-110)."""
-    def wrap_refscalar(self, path, spec, val):
-        spev = self._params['other']
-        for part in spec.ref.split('.'):
-            spev = spev[part]
-        spev *= val if val is not None else spec.default
-        return spev
+class View(object):
+    """
+    Read-only view of ``doc`` under ``schema``.  Attribute (or item) access resolves one child:
+    a nested mapping gives another View, a leaf gives its value or the schema's default, and the two
+    leaf kinds that need context — animated splines and profile references — are built by
+    ``leaves[Spline]`` / ``leaves[RefScalar]`` when given.  Iteration covers the keys that are
+    present in the document, sorted as strings (the order the packer lays xforms out in).
+    """
+    __slots__ = ('_doc', '_schema', '_leaves')
+
+    def __init__(self, doc, schema=None, leaves=None):
+        if schema is None:
+            kind = doc.get('type')
+            if kind not in toplevels:
+                raise ValueError('unrecognised document type %r' % (kind,))
+            schema = toplevels[kind]
+        object.__setattr__(self, '_doc', doc)
+        object.__setattr__(self, '_schema', schema)
+        object.__setattr__(self, '_leaves', leaves or {})
+
+    def raw(self):
+        """The underlying document (only what the file says: no defaults)."""
+        return self._doc
+
+    def child_schema(self, key):
+        return self._schema.type if isinstance(self._schema, Map) else self._schema[key]
+
+    def _resolve(self, node, value):
+        build = self._leaves.get(type(node))
+        if build is not None:
+            return build(node, value)
+        if isinstance(node, (dict, Map)):
+            return View(value or {}, node, self._leaves)
+        if isinstance(node, List):
+            return [self._resolve(node.type, item) for item in _or_default(value, node)]
+        if isinstance(node, Enum):
+            return value or node.default
+        if isinstance(node, (Scalar, RefScalar)):
+            return _or_default(value, node)
+        return value                                 # splines without a builder, strings, palettes
+
+    def __getattr__(self, key):
+        if key.startswith('__'):
+            raise AttributeError(key)
+        return self._resolve(self.child_schema(key), self._doc.get(key))
+
+    def __getitem__(self, key):
+        return getattr(self, str(key))
+
+    def __setattr__(self, key, value):
+        raise AttributeError('views are read-only')
+
+    def keys(self):
+        return sorted(self._doc)
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._doc)
+
+    def __contains__(self, key):
+        self.child_schema(key)                       # unknown names are an error, not "absent"
+        return key in self._doc
+
+
+def genome_view(gnm, scale):
+    """Genome whose splines evaluate on the host; ``scale`` = time.duration (velocities are per unit
+    of genome time)."""
+    return View(gnm, leaves={Spline: lambda node, value: SplineEval(_or_default(value, node), scale, node.interp)})
+
+
+def profile_view(prof, schema, genome):
+    """Profile whose RefScalars are the referenced genome spline times the profile's number
+    (cuburn/genome/use.py:100-110): ``gprof.spp(tc)`` = profile spp x genome ``spp`` curve at tc."""
+    def ref(node, value):
+        target = genome
+        for part in node.ref.split('.'):
+            target = target[part]
+        factor = _or_default(value, node)
+        # the referenced leaf is a curve (spp, frame_width, ...) or a plain number (time.duration)
+        return target.scaled(factor) if isinstance(target, SplineEval) else target * factor
+    return View(prof, schema, leaves={RefScalar: ref})

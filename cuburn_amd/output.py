@@ -39,6 +39,9 @@ class Output(object):
             return {}, []
         return {self.suffix: io.BytesIO(np.ascontiguousarray(buf).tobytes())}, []
 
+    def abort(self):
+        """Drop whatever a half-written output holds (encoder processes, temporary files)."""
+
 
 def _png_bytes(buf):
     """Minimal PNG writer (8-bit RGB / RGBA), no external imaging library needed."""
@@ -176,7 +179,7 @@ def get_suffix(codec, alpha=False):
 
 def get_output_for_profile(gprof):
     """Output module for the profile's ``output`` block (cuburn/output.py:421-436)."""
-    opts = dict(gprof.output._val)
+    opts = dict(gprof.output.raw())
     handler = opts.pop('type', 'jpeg')
     if handler in ('jpeg', 'png'):
         return PILOutput(codec=handler, **opts)
@@ -197,5 +200,5 @@ def get_output_for_profile(gprof):
 
 
 def get_suffix_for_profile(gprof):
-    opts = dict(gprof.output._val)
+    opts = dict(gprof.output.raw())
     return get_suffix(opts.get('type', 'jpeg'), bool(opts.get('alpha')))

@@ -10,7 +10,7 @@ import argparse
 import numpy as np
 
 from .genome.specs import toplevels
-from .genome.use import RefWrapper, SplineWrapper
+from .genome.use import genome_view, profile_view
 
 BUILTIN = {
     '1080p': dict(width=1920, height=1080),
@@ -82,7 +82,7 @@ def get_from_args(args):
 def wrap(prof, gnm):
     """Genome-adjusted profile view: RefScalars scale the genome's splines (cuburn/profile.py:97-105)."""
     scale = gnm.get('time', {}).get('duration', 1)
-    return RefWrapper(prof, toplevels['profile'], other=SplineWrapper(gnm, scale=scale))
+    return profile_view(prof, toplevels['profile'], genome_view(gnm, scale))
 
 
 def enumerate_times(gprof):
@@ -116,8 +116,8 @@ def enumerate_jobs(gprof, basename, args, resume=None):
     """
     from . import output
     stem = os.path.join(args.dir, basename if args.name is None else args.name)
-    if args.subdir and not os.path.isdir(stem):
-        os.mkdir(stem)
+    if args.subdir:
+        os.makedirs(stem, exist_ok=True)             # every per-GPU process gets here: no race on the directory
     pattern = stem + ('/' if args.subdir else '_') + '%05d' + args.suffix
     jobs = [(pattern % number, times) for number, times in enumerate_times(gprof)]
     if args.resume if resume is None else resume:

@@ -244,13 +244,12 @@ class RenderManager(object):
     # unless the image has more than 8191 tiles, else direct packed global atomics.  Both give the
     # same histogram.
     accum_mode = 'auto'
-    # Write-disabled iterations per walker at the start of a frame.  The reference's value is 256
-    # (render.py:215: one whole round block, a by-product of its launch granularity); flam3 uses 15.
-    # The CPU device model shows the start-up transient is gone after 16 iterations for the
-    # BASELINE flames even when only 8 write rounds follow (DESIGN.md §4.1 'fuse'); 64 keeps a 4x
-    # margin.  Set to 256 (or FLAME_FUSE=256) for the reference's literal schedule — a genome made of ONE
-    # slowly contracting xform can still show its start-up transient at 64 (DESIGN.md §5 'Fuse').
-    fuse = int(os.environ.get('FLAME_FUSE', 64))
+    # Write-disabled iterations per walker at the start of a frame: the reference's 256 (render.py:215,
+    # iter.py:209-216,298-300: every point set is re-seeded per frame and spends one whole 256-round block
+    # un-plotted).  The BASELINE flames are converged after 16 (DESIGN.md §5 'Fuse'), but a genome of ONE
+    # slowly contracting xform still shows its start-up transient at 64 — so the reference's schedule is
+    # the default, and a shorter fuse (attribute or FLAME_FUSE) is the caller's decision.
+    fuse = int(os.environ.get('FLAME_FUSE', 256))
 
     def __init__(self, device=None, nslots=None, host_seed=None, stream=None):
         if device is None:

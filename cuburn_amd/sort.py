@@ -36,7 +36,10 @@ class Sorter(object):
 
     def sort(self, dst, src, size, lo_bit=0, ignore_max=False, stream=None, count=False):
         """One pass.  ``ignore_max``: keys equal to 0xffffffff are dropped; with ``count`` the number of
-        keys written is read back into ``self.nvalid`` (synchronises)."""
+        keys written is read back into ``self.nvalid`` (synchronises).  Passes run on the first stream of
+        the native context (pass a stream to Framebuffers to choose it): a per-call ``stream`` is refused."""
+        if stream is not None:
+            raise ValueError('Sorter runs on its context\'s stream; create the Framebuffers with stream=... instead')
         if not 0 < size <= self.max_size:
             raise ValueError('size %d outside (0, %d]' % (size, self.max_size))
         n = C.c_uint32()
@@ -57,7 +60,7 @@ class Sorter(object):
                 break
             keep, self.radix_bits = self.radix_bits, bits
             try:
-                self.sort(out, cur, size, lo)
+                self.sort(out, cur, size, lo, stream=stream)
             finally:
                 self.radix_bits = keep
             cur, out, other = out, other, out

@@ -217,7 +217,8 @@ int fl_output(fl_ctx *ctx, uint32_t w, uint32_t h, int fmt, void *host_out, uint
  * pass is not stable and its multi-pass sort is marked broken, sort.py:437-441,455-458).
  * ignore_max: keys equal to 0xffffffff are dropped (sort.py:449-452); *nvalid (optional, makes the
  * call synchronous) receives the number of keys written.  dst and src are device addresses and must
- * not overlap; the pass runs on the context's current stream.  Not used by the render path — like
+ * not overlap; every pass runs on the context's FIRST stream (the caller's, if one was given to
+ * fl_ctx_create), so consecutive passes are ordered.  Not used by the render path — like
  * the reference's sorter (imported by render.py:19, never called). */
 int fl_sort_u32(fl_ctx *ctx, uint64_t dst_dev, uint64_t src_dev, uint32_t n, uint32_t lo_bit, uint32_t nbits, int ignore_max,
                 uint32_t *nvalid);

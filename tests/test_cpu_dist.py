@@ -275,3 +275,48 @@ def test_cfg4_sixty_frames_shard_and_gather_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'CFG4_OK' in outs[0]
+
+
+def test_frame_gather_refuses_to_reuse_a_block_with_outstanding_frames():
+    """A queue deeper than the gather block would hand out a tensor whose previous frame is still
+    being rendered (or not yet gathered): slot() raises instead, and run_frame_loop checks up front."""
+    import pytest
+    import torch
+    from cuburn_amd import distributed as D
+    g = D.FrameGather((1, 1, 4), torch.uint8, torch.device('cpu'), block=2)
+    for _ in range(4):                               # both blocks handed out, nothing submitted
+        g.slot()
+    with pytest.raises(RuntimeError):
+        g.slot()                                     # would re-enter block 0: a and b never submitted
+    g2 = D.FrameGather((1, 1, 4), torch.uint8, torch.device('cpu'), block=1)
+    with pytest.raises(ValueError):
+        D.run_frame_loop(lambda slot: (None, None), 4, depth=2, gather=g2)
+
+
+def _bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    return p, lines
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts a child torch.distributed.run with two ranks
+    (the reference's dispatcher starts its own workers, distribute.py:131-186) and relays rank 0's line;
+    --dry-run exercises exactly that control flow (process group, world-size check, barrier, reduction)
+    without rendering, so it runs without a GPU.  The N = 1 path starts nothing."""
+    import json
+    p, lines = _bench(['--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+    p, lines = _bench(['--gpus', '1', '--dry-run'])
+    assert p.returncode == 0 and json.loads(lines[0])['n_gpus'] == 1
+    # a launcher that started the wrong number of ranks is an error, not a silent one-GPU run
+    p, lines = _bench(['--gpus', '2', '--dry-run'], env={'WORLD_SIZE': '1', 'RANK': '0'})
+    assert p.returncode != 0 and not lines

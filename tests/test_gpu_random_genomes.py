@@ -140,7 +140,7 @@ def test_random_genome_parity(mgr, mgr_prod, seed):
     # short iterate vs the flam3-style game on the oracle's blocks
     n = 2 ** 24
     run = C.c_uint64()
-    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(n), 64, 1, C.byref(run)))
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(n), mgr.fuse, 1, C.byref(run)))     # the default schedule (fuse 256)
     nbins = dim.ah * dim.astride
     front = mgr.fb.read('front', (nbins, 4), np.float32).astype(np.float64)
     assert np.isfinite(front).all()
@@ -157,6 +157,47 @@ def test_random_genome_parity(mgr, mgr_prod, seed):
         bg, br = blocks(front), blocks(refh)
         l1 = np.abs(bg / bg.sum() - br / br.sum()).sum()
         assert l1 < 0.05, l1
+
+
+def _blocks16(a, dim):
+    H, W = dim.ah // 16 * 16, dim.astride // 16 * 16
+    return a.reshape(dim.ah, dim.astride)[:H, :W].reshape(H // 16, 16, W // 16, 16).sum((1, 3))
+
+
+# Genomes of ONE xform: a lone map converges to its orbit at its own contraction rate, with no averaging
+# over xform choices — the class for which a fuse of 64 was measurably too short (seed 209: cross + fan2 +
+# linear, block L1 0.11 at fuse 64, 0.010 at 256).  Everything here runs at RenderManager's DEFAULTS,
+# through queue_frame: no explicit fuse, production slots.  The CPU sample uses 64 trajectories (eight
+# trajectories of a map that does not mix are not a distribution).
+@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102])
+def test_single_xform_genome_default_schedule(seed):
+    gnm, prof = random_genome(seed)
+    assert len(gnm['xforms']) == 1
+    prof = dict(prof, filter_order=[])                       # the accumulator itself is compared
+    gprof = profile.wrap(prof, gnm)
+    m = render.RenderManager(device=0, host_seed=23)
+    assert m.fuse == 256 and m.fb.nslots == 1536             # cuburn/render.py:215
+    rdr = render.Renderer(gnm, gprof)
+    tc = 0.37
+    evt, _ = m.queue_frame(rdr, gnm, gprof, tc)
+    evt.synchronize()
+    dim = m.fb.calc_dim(gprof.width, gprof.height)
+    dens = m.fb.read('front', (dim.ah * dim.astride, 4), np.float32).astype(np.float64)[:, 3]
+    nrun = m.last_nsamples
+    F = prepare(gnm, prof, tc, nslots=m.fb.nslots)
+    n = 2 ** 26
+    refh, _, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, 64)
+    refd = refh.astype(np.float64)[:, 3]
+    fg, fr = dens.sum() / nrun, refd.sum() / n
+    assert abs(fg - fr) < 0.005 + 0.01 * fr, (fg, fr)
+    if fr > 0.02:
+        bg, br = _blocks16(dens, dim), _blocks16(refd, dim)
+        l1 = np.abs(bg / bg.sum() - br / br.sum()).sum()
+        # shot noise of both samples: sum over blocks of sqrt(2 / pi * p * (1/Ng + 1/Nr))
+        p = br / br.sum()
+        floor = np.sqrt(2 / np.pi * p * (1.0 / dens.sum() + 1.0 / refd.sum())).sum()
+        assert l1 < 0.02 + 3 * floor, (l1, floor)
+    m.fb.free()
 
 
 def _variation_genome(names):
