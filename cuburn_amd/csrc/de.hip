@@ -42,6 +42,8 @@
 #include "tone_device.h"
 #include <utility>
 #include <cmath>
+#include <algorithm>
+#include <cstdlib>
 
 struct DeCoefs { float k[7]; };
 struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
@@ -165,6 +167,10 @@ __device__ float de_b2_global(const float4 *__restrict__ N, const fl_dim &d, int
 // takes the step's buffer AND the accumulators as read-write operands: that is what pins the
 // arithmetic of step g-1 before it and the arithmetic of step g after it.
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef DE_PK
+#define DE_PK 0      /* measured: 59.3 us against 58.6 per direction — v_pk_fma_f32 costs what the two v_fma_f32 it replaces cost */
+#endif
 struct DeTap { f4v a, b; };         // A at tap r+1 (the next pixel), B at tap r = (|ds|*w^dpow, cs*|n|^2, H+ | g/(avg+1e-6), H-)
 
 #define DE_RD128(dst, addr, boff) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(boff) : "memory")
@@ -208,7 +214,10 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     float wprev = G::HOIST ? 0.0f : bA[TOFF(-16)].w;
     const float4 p0 = bA[TOFF(-15)];
     f4v pix = {p0.x, p0.y, p0.z, p0.w};
-    float ox = 0.0f, oy = 0.0f, oz = 0.0f, ow = 0.0f, wsum = 0.0f;
+    // accumulators as register pairs: (sum f*w*nx, sum f*w*ny) and (sum f*w*nz, sum f*w) take one v_pk_fma_f32 each
+    // (1.6 issue slots instead of 2; DE_PK=0 keeps scalar accumulators)
+    f2v oxy = {0.0f, 0.0f}, ozw = {0.0f, 0.0f};
+    float wsum = 0.0f;
 
     DeTap L[2][2];
     auto issue = [&](auto gc) __attribute__((always_inline)) {
@@ -225,11 +234,11 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
         if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
         constexpr int inflight = g + 1 < 16 ? de_tap_reads<P>(-15 + (g + 1) * 2) + de_tap_reads<P>(-14 + (g + 1) * 2) : 0;
         DeTap (&T)[2] = L[g & 1];
-        asm volatile("s_waitcnt lgkmcnt(%20)"
+        asm volatile("s_waitcnt lgkmcnt(%[n])"
                      : "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b),
-                       "+v"(aA), "+v"(aB), "+v"(ox), "+v"(oy), "+v"(oz), "+v"(ow), "+v"(wsum),
+                       "+v"(aA), "+v"(aB), "+v"(oxy), "+v"(ozw), "+v"(wsum),
                        "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(thr), "+v"(Kp), "+v"(cds), "+v"(biasp)
-                     : "n"(inflight));
+                     : [n] "n"(inflight));
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int r = -15 + g * 2 + k;
@@ -247,7 +256,13 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
                 const float factor = spk.s[r < 0 ? -r : r] * fexp2(e);
                 wsum += factor;
                 const float fw = factor * pix.w;
-                ox = fmaf(fw, pix.x, ox); oy = fmaf(fw, pix.y, oy); oz = fmaf(fw, pix.z, oz); ow += fw;
+#if DE_PK
+                const f2v nxy = {pix.x, pix.y}, nzw = {pix.z, pix.w}, ff = {fw, fw}, fz = {fw, factor};
+                oxy = __builtin_elementwise_fma(ff, nxy, oxy);
+                ozw = __builtin_elementwise_fma(fz, nzw, ozw);                 // sum f*w*nz | sum f*w
+#else
+                oxy.x = fmaf(fw, pix.x, oxy.x); oxy.y = fmaf(fw, pix.y, oxy.y); ozw.x = fmaf(fw, pix.z, ozw.x); ozw.y += fw;
+#endif
                 wprev = pix.w;
                 if (r < 15 || !G::HOIST) pix = T[k].a;
             }
@@ -261,9 +276,10 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
 #undef TOFFB
     // out.xyz = sum f*w*n, out.w = sum f*w: the normalised colour is their ratio (the 1/weightsum of the
     // reference cancels), the density is out.w / (weightsum + 1e-10)
+    const float ow = ozw.y;
     const float wn = ow * frcp(wsum + 1e-10f);
     const float rn = ow >= 1.17549435e-38f ? frcp(ow) : 0.0f;   // v_rcp_f32 of a denormal is +inf
-    res = make_float4(ox * rn, oy * rn, oz * rn, wn);
+    res = make_float4(oxy.x * rn, oxy.y * rn, ozw.x * rn, wn);
 }
 
 // Normalise the accumulator into N (first pass input); with YUV -> RGB in front when the chain starts with `yuv`
@@ -386,7 +402,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         }
         const float ra = frcp(den + 1.0e-6f) * gspeed;
         const float4 n = sA[idx];
-        pb[it].x = ads * fpow(n.w, dpow);
+        pb[it].x = ads * de_pow(n.w, dpow);
         pb[it].y = cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x));
         if (G::HOIST) {
             // next / prev of a tap at this position are its neighbours one step along the direction
@@ -437,6 +453,274 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     }
 }
 
+// ---- band walker ------------------------------------------------------------------------------------
+// k_de_dir stages a 32-row tile with its 24-row halos for every 32 rows of output: 2.5 staged pixels per
+// output pixel, each with its two blur values, w^dpow, two exponentials — 205 of the kernel's 763 issue
+// slots per pixel.  Here a workgroup owns a sheared column BAND over a SEGMENT of rows and walks down it,
+// keeping the staged window in LDS: after a step of `adv` rows the planes move up by `adv` rows (a block
+// move through registers, ~5 % of the LDS traffic of the step's taps) and only the new rows are loaded and
+// prepared — every row of a segment is staged once, plus the halos at the segment's ends.
+//   * The two dense preparation planes (density, first blur) live in the space of plane B's new rows, which
+//     is free until those rows are written.
+//   * Steps have equal height: adv = rows of the segment / steps, rounded up to an even number (<= TH): a
+//     last step of 10 rows costs what a step of 32 costs (measured), 5 steps of 28 cost 5 x 28.
+//   * Bands wrap around the image: column x of a sheared band is taken modulo W = bands x TW, so every band
+//     is full over all its rows and the workgroup count is bands x segments <= two per CU — all resident
+//     at once, equal work, no second round for the bands that would stick out of the image.  W exceeds the
+//     image width by more than twice the reach of any staged position beyond an image edge, so a wrapped
+//     column outside the image is either "right of the right edge" or "left of the left edge" (nearer gap
+//     end), which is all the reference's clamped fetches need.
+// Same LDS layout, same tap loop, same arithmetic in the same order as k_de_dir: bit-identical results
+// (test_de_band_equals_tiles).
+template <int P> struct DeBand {
+    using G = DeGeo<P>;
+    static constexpr int RB1 = de_dy(P, 3) < 0 ? -de_dy(P, 3) : de_dy(P, 3);      // rows reached by the first blur
+    static constexpr int RB2 = de_dy(P, 6) < 0 ? -de_dy(P, 6) : de_dy(P, 6);      // ... by the second
+    static constexpr int LA = G::HU - G::HBU;                                     // both: what a B row needs beyond itself
+    static_assert(LA == RB1 + RB2, "halo of plane A = tap reach + both blurs");
+    // smallest step for which the preparation planes fit into the new rows of plane B
+    static constexpr int min_adv()
+    {
+        int a = 2;
+        while (2 * (a + 2 * LA) * G::COLS * 4 > a * G::BCOLS * 16) a += 2;
+        return a;
+    }
+    static constexpr int MIN_ADV = min_adv();
+    static_assert(MIN_ADV <= G::TH / 2 + 2, "two steps must be able to share a segment of TH + 1 rows");
+    // how far beyond an image edge (in x) a staged position that matters can lie: the taps' and blurs' reach
+    static constexpr int xreach()
+    {
+        int m = 0;
+        for (int r = -16; r <= 16; ++r) { const int a = de_dx(P, r) < 0 ? -de_dx(P, r) : de_dx(P, r); m = a > m ? a : m; }
+        const int b2 = de_dx(P, 6) < 0 ? -de_dx(P, 6) : de_dx(P, 6), b1 = de_dx(P, 3) < 0 ? -de_dx(P, 3) : de_dx(P, 3);
+        return m + b2 + b1 + G::HV + 2;
+    }
+    static constexpr int GAP = 2 * xreach() + 2;
+};
+
+struct DeBandPos { int bx0, yseg, wtot; };      // column 0 of the band at the segment's first row; that row; wrap width
+
+// wrapped image column of band column v (may be negative / beyond TW: halo) in the row `rel` rows below the segment's first
+template <int P>
+__device__ __forceinline__ int de_band_x(const DeBandPos &bp, int rel, int v)
+{
+    int x = (bp.bx0 + ((rel * DeGeo<P>::K) >> 1) + v) % bp.wtot;
+    return x < 0 ? x + bp.wtot : x;
+}
+// the pixel a wrapped column stands for when it lies in the gap: the nearer image edge
+__device__ __forceinline__ int de_band_clampx(const DeBandPos &bp, int xw, int xmax)
+{
+    return xw <= xmax ? xw : (xw - xmax <= bp.wtot - xw ? xmax : 0);
+}
+
+// edge-clamped load of plane A's element idx (rows counted from the plane's row ul0; rbase = rel of the plane's row 0)
+template <int P>
+__device__ __forceinline__ float4 de_band_load(const float4 *__restrict__ N, const fl_dim &d, int idx, int ul0, const DeBandPos &bp, int rbase)
+{
+    using G = DeGeo<P>;
+    const int ul = idx / G::COLS + ul0, vl = idx % G::COLS;
+    const int rel = rbase + ul;
+    const int gx = de_band_clampx(bp, de_band_x<P>(bp, rel, vl - G::HV), (int)d.astride - 1);
+    const int gy = de_clampi(bp.yseg + rel, 0, (int)d.ah - 1);
+    return N[(uint32_t)(gy * (int)d.astride + gx)];
+}
+
+// Prepare nb rows of plane B starting at its row ub0 (0, BROWS: the whole window; BROWS - adv, adv: the new rows
+// of a step).  rbase = row of plane A's row 0 relative to the segment's first row; rows_need: B rows beyond
+// this count (from ub0) are not needed by any output of the segment and are skipped.
+template <int P>
+__device__ __forceinline__ void de_band_prepare(const float4 *__restrict__ N, const fl_dim &d, float4 *sA, float4 *sB, int tid,
+                                                int ub0, int nb, const DeBandPos &bp, int rbase, int rows_need, const DeCoefs &kc,
+                                                float cs2, float ads, float dpow, float gspeed)
+{
+    using G = DeGeo<P>;
+    using Bd = DeBand<P>;
+    const int wrows = nb + 2 * Bd::LA, wpx = wrows * G::COLS;
+    float *sW = reinterpret_cast<float *>(sB + ub0 * G::BCOLS);          // dense density plane: rows ub0 .. ub0 + wrows of plane A
+    float *s1 = sW + wpx;                                                // first blur, same geometry
+    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
+    const int wneed = (min(rows_need, nb) + 2 * Bd::LA) * G::COLS;       // temp-plane elements that matter
+    // does any position of these rows leave the image?  (block-uniform: rows, or columns that reach the gap)
+    const int rel0 = rbase + ub0, rel1 = rbase + ub0 + wrows - 1;
+    const int sh0 = (rel0 * G::K) >> 1, sh1 = (rel1 * G::K) >> 1;
+    bool border = bp.yseg + rel0 < 0 || bp.yseg + rel1 > ymax;
+    {
+        int lo = (bp.bx0 + min(sh0, sh1) - G::HV - 1) % bp.wtot;
+        lo = lo < 0 ? lo + bp.wtot : lo;
+        border = border || lo + (max(sh0, sh1) - min(sh0, sh1)) + G::TW + 2 * G::HV + 2 > xmax;
+    }
+    const float4 *sAw = sA + ub0 * G::COLS;
+
+    for (int idx = tid; idx < wneed; idx += 1024) sW[idx] = sAw[idx].w;
+    __syncthreads();
+    // first blur (7 taps, step 1), in the reference's summation order
+    for (int idx = tid; idx < wneed; idx += 1024) {
+        const int wl = idx / G::COLS, vl = idx - wl * G::COLS;
+        if (wl < Bd::RB1 || wl >= wrows - Bd::RB1) continue;
+        const int rel = rbase + ub0 + wl;
+        const bool par = (rel & 1) != 0;
+        float den = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int o0 = G::off(0, de_dx(P, j - 3), de_dy(P, j - 3)), o1 = G::off(1, de_dx(P, j - 3), de_dy(P, j - 3));
+            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
+            den = fmaf(sW[idx + o], kc.k[j], den);
+        }
+        if (border) {
+            const int gxw = de_band_x<P>(bp, rel, vl - G::HV), gyu = bp.yseg + rel;
+            if (gxw > xmax || gyu < 0 || gyu > ymax)                    // virtual position: the blur AT the clamped position
+                den = de_b1_global<P>(N, d, de_band_clampx(bp, gxw, xmax), de_clampi(gyu, 0, ymax), kc);
+        }
+        s1[idx] = den;
+    }
+    __syncthreads();
+    // per-pixel tap terms of the nb rows; held in registers until every thread is done with the planes
+    constexpr int NITB = (G::NPXB + 1023) / 1024;
+    const int nbpx = min(rows_need, nb) * G::BCOLS;
+    float4 pb[NITB];
+#pragma unroll
+    for (int it = 0; it < NITB; ++it) {
+        const int bidx = it * 1024 + tid;
+        pb[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (bidx >= nbpx) continue;
+        const int ubr = bidx / G::BCOLS, vb = bidx - ubr * G::BCOLS;          // row within the nb rows
+        const int wl = ubr + Bd::LA, vl = vb + G::HV - G::HBV;
+        const int idx = wl * G::COLS + vl;
+        const int rel = rbase + ub0 + wl;
+        const bool par = (rel & 1) != 0;
+        float den = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int o0 = G::off(0, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3))), o1 = G::off(1, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3)));
+            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
+            den = fmaf(s1[idx + o], kc.k[i], den);
+        }
+        if (border) {
+            const int gxw = de_band_x<P>(bp, rel, vl - G::HV), gyu = bp.yseg + rel;
+            if (gxw > xmax || gyu < 0 || gyu > ymax)
+                den = de_b2_global<P>(N, d, de_band_clampx(bp, gxw, xmax), de_clampi(gyu, 0, ymax), kc);
+        }
+        const float ra = frcp(den + 1.0e-6f) * gspeed;
+        const float4 n = sAw[idx];
+        pb[it].x = ads * de_pow(n.w, dpow);
+        pb[it].y = cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x));
+        if (G::HOIST) {
+            constexpr int dn = G::off(0, de_dx(P, 1), de_dy(P, 1));
+            const float g = (sW[idx + dn] - sW[idx - dn]) * ra;
+            pb[it].z = fexp2(g);
+            pb[it].w = fexp2(-g);
+        } else {
+            pb[it].z = ra;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NITB; ++it) {
+        const int bidx = it * 1024 + tid;
+        if (bidx < nb * G::BCOLS) sB[ub0 * G::BCOLS + bidx] = pb[it];
+    }
+    __syncthreads();
+}
+
+template <int P, int OUT>
+__global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
+k_de_band(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
+          float cs2, float ads, float dpow, float gspeed, uint32_t nbands, uint32_t nseg, uint32_t seg_rows, DeTail tail)
+{
+    using G = DeGeo<P>;
+    using Bd = DeBand<P>;
+    static_assert(P != 0, "the horizontal direction keeps its 8 x 128 tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *sA = reinterpret_cast<float4 *>(smem);
+    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPX * 16);
+    const int tid = threadIdx.x;
+    const uint32_t seg = blockIdx.x % nseg, band = blockIdx.x / nseg;
+    DeBandPos bp;
+    bp.yseg = (int)(seg * seg_rows);
+    bp.bx0 = (int)band * G::TW;
+    bp.wtot = (int)nbands * G::TW;
+    const int rows_here = min((int)seg_rows, (int)d.ah - bp.yseg);
+    if (rows_here <= 0) return;
+    const int xmax = (int)d.astride - 1;
+    // equal steps: as few as fit (TH rows each at most), the same even number of rows in each
+    const int nsteps = (rows_here + G::TH - 1) / G::TH;
+    const int adv = nsteps == 1 ? G::TH : max(Bd::MIN_ADV, (((rows_here + nsteps - 1) / nsteps) + 1) & ~1);
+
+    // ---- the first window: all of plane A, all of plane B -----------------------------------------
+    for (int idx = tid; idx < G::NPX; idx += 1024) sA[idx] = de_band_load<P>(N, d, idx, 0, bp, -G::HU);
+    __syncthreads();
+    de_band_prepare<P>(N, d, sA, sB, tid, 0, G::BROWS, bp, -G::HU, rows_here + 2 * G::HBU, kc, cs2, ads, dpow, gspeed);
+
+    for (int s = 0;; ++s) {
+        // Everything a phase needs is derived from an opaque copy of the thread id inside the phase: nothing
+        // but the id itself is live across the tap loop, which owns the 64 registers (values the compiler would
+        // otherwise hoist out of this loop end up in scratch).
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        // ---- taps ------------------------------------------------------------------------------
+        // thread -> output pixel of a step (as k_de_dir): a wave covers rows of equal parity
+        const int wv = t >> 6, lane = t & 63;
+        constexpr int RPW = 64 / G::TW;
+        const int ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW), ov = lane % G::TW;
+        const int ci = (ou + G::HU) * G::COLS + ov + G::HV;
+        const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
+        const int rel = s * adv + ou;
+        const bool inside = ou < adv && rel < rows_here && de_band_x<P>(bp, rel, ov) <= xmax;
+        if (__ballot(inside) != 0ull) {                             // wave-uniform: rows past the step / segment, columns in the gap
+            float cs2l = cs2;
+            asm volatile("" : "+s"(cs2l));                          // (its multiples are recomputed per step, not kept in registers)
+            float4 res;
+            if ((G::K & 1) && (wv & 1)) de_tap_loop<P, 1>(sA, sB, ci, cb, cs2l, spk, res);
+            else de_tap_loop<P, 0>(sA, sB, ci, cb, cs2l, spk, res);
+            // the output position again, from the thread id
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int wv2 = t2 >> 6, lane2 = t2 & 63;
+            const int ou2 = (wv2 >> 1) * (2 * RPW) + (wv2 & 1) + 2 * (lane2 / G::TW);
+            const int rel2 = s * adv + ou2;
+            const int xo2 = de_band_x<P>(bp, rel2, lane2 % G::TW);
+            if (ou2 < adv && rel2 < rows_here && xo2 <= xmax) {
+                if (OUT) {                                          // as k_de_finish_tone (filters.hip)
+                    float4 p = make_float4(res.x * res.w, res.y * res.w, res.z * res.w, res.w);
+                    if (tail.do_log) p = logscale_px(p, tail.k1, tail.k2);
+                    if (tail.do_clip) p = colorclip_px(p, tail.vib, tail.highpow, tail.gam, tail.lin, tail.lingam);
+                    res = p;
+                }
+                Nout[(uint32_t)((bp.yseg + rel2) * (int)d.astride + xo2)] = res;
+            }
+        }
+        if ((s + 1) * adv >= rows_here) break;
+        int u = tid;
+        asm volatile("" : "+v"(u));
+        // ---- the window moves down by adv rows --------------------------------------------------------
+        const int rbase = (s + 1) * adv - G::HU;
+        // output rows from the next step on; as many of the adv new rows of either plane are needed by them
+        // (a new row of plane A / B lies HU / HBU rows below the step's first output row)
+        const int new_need = min(rows_here - (s + 1) * adv, adv);
+        const int keep_a = (G::ROWS - adv) * G::COLS, keep_b = (G::BROWS - adv) * G::BCOLS;
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        constexpr int NK = (G::NPX + 1023) / 1024;
+        static_assert(NK <= 3 && (G::NPXB + 1023) / 1024 <= 3, "three elements per thread at most");
+        const float4 na0 = u < new_need * G::COLS ? de_band_load<P>(N, d, u, G::ROWS - adv, bp, rbase) : zero;
+        const float4 na1 = u + 1024 < new_need * G::COLS ? de_band_load<P>(N, d, u + 1024, G::ROWS - adv, bp, rbase) : zero;
+        const float4 ka0 = sA[min(u, keep_a - 1) + adv * G::COLS], ka1 = sA[min(u + 1024, keep_a - 1) + adv * G::COLS],
+                     ka2 = sA[min(u + 2048, keep_a - 1) + adv * G::COLS];
+        const float4 kb0 = sB[min(u, keep_b - 1) + adv * G::BCOLS], kb1 = sB[min(u + 1024, keep_b - 1) + adv * G::BCOLS],
+                     kb2 = sB[min(u + 2048, keep_b - 1) + adv * G::BCOLS];
+        __syncthreads();
+        if (u < keep_a) sA[u] = ka0;
+        if (u + 1024 < keep_a) sA[u + 1024] = ka1;
+        if (u + 2048 < keep_a) sA[u + 2048] = ka2;
+        if (u < keep_b) sB[u] = kb0;
+        if (u + 1024 < keep_b) sB[u + 1024] = kb1;
+        if (u + 2048 < keep_b) sB[u + 2048] = kb2;
+        if (u < adv * G::COLS) sA[keep_a + u] = na0;
+        if (u + 1024 < adv * G::COLS) sA[keep_a + u + 1024] = na1;
+        __syncthreads();
+        de_band_prepare<P>(N, d, sA, sB, u, G::BROWS - adv, adv, bp, rbase, new_need, kc, cs2, ads, dpow, gspeed);
+    }
+}
+
 template <bool YUV>
 __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__restrict__ N, const float4 *__restrict__ src)
 {
@@ -462,10 +746,36 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
                        cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
 }
 
+// Band walker: bands x segments <= two workgroups per CU (all resident at once, equal rows each);
+// seg_env > 0 (FLAME_DE_SEG_ROWS) sets the segment length (tests).
+template <int P, int OUT>
+static void launch_de_band_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
+                               float cs2, float ads, float dpow, float gspeed, DeTail tail, int seg_env)
+{
+    using G = DeGeo<P>;
+    using Bd = DeBand<P>;
+    static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
+    static unsigned long long attr = 0;
+    ensure_max_dynamic_lds((const void *)k_de_band<P, OUT>, attr);
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }
+        slots = 2 * cus;
+    }
+    const uint32_t nbands = (d.astride + (uint32_t)Bd::GAP + G::TW - 1) / G::TW;
+    uint32_t nseg = std::max(1u, std::min((uint32_t)slots / nbands, std::max(1u, d.ah / (uint32_t)G::TH)));
+    uint32_t seg_rows = (d.ah + nseg - 1) / nseg;
+    if (seg_env > 0) seg_rows = (uint32_t)seg_env;
+    nseg = (d.ah + seg_rows - 1) / seg_rows;
+    hipLaunchKernelGGL((k_de_band<P, OUT>), dim3(nbands * nseg), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
+                       cs2, ads, dpow, gspeed, nbands, nseg, seg_rows, tail);
+}
+
 // in_mode (pattern 0 only): 0 = N holds the normalised image, 1 = the raw accumulator, 2 = the raw YUV
 // accumulator.  tail (pattern 7 only, may be null): un-normalise + the tone filters riding along.
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail)
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail, int form)
 {
     DeCoefs kc;
     for (int i = 0; i < 7; ++i) kc.k[i] = coefs7[i];
@@ -475,7 +785,22 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
     const DeTail none = {};
+    const bool tiles = (form & 1) != 0;
+    const int seg_rows = form >> 8;
 #define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none)
+#define DB(P, O) launch_de_band_one<P, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none, seg_rows)
+    if (!tiles && pattern >= 1 && pattern <= 7) {
+        switch (pattern) {
+        case 1: DB(1, 0); break;
+        case 2: DB(2, 0); break;
+        case 3: DB(3, 0); break;
+        case 4: DB(4, 0); break;
+        case 5: DB(5, 0); break;
+        case 6: DB(6, 0); break;
+        default: if (tail) DB(7, 1); else DB(7, 0); break;
+        }
+        return;
+    }
     switch (pattern) {
     case 0: if (in_mode == 2) DE(0, 2, 0); else if (in_mode == 1) DE(0, 1, 0); else DE(0, 0, 0); break;
     case 1: DE(1, 0, 0); break;
@@ -488,6 +813,7 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     default: break;
     }
 #undef DE
+#undef DB
 }
 
 void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv)

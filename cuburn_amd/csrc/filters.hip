@@ -103,7 +103,7 @@ k_bilateral(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ src, 
     float4 cen = src[gi];
     const float cdrcp = frcp(cen.w + 1.0e-6f);
     cen.x *= cdrcp; cen.y *= cdrcp; cen.z *= cdrcp;
-    const float cpowden = fpow(cen.w, dpow);
+    const float cpowden = de_pow(cen.w, dpow);
 
     float4 out = make_float4(0, 0, 0, 0);
     float weightsum = 0.0f;
@@ -122,7 +122,7 @@ k_bilateral(fl_dim d, float4 *__restrict__ dst, const float4 *__restrict__ src, 
             const float yd = pix.x * pdrcp - cen.x, ud = pix.y * pdrcp - cen.y, vd = pix.z * pdrcp - cen.z;
             cdiff = yd * yd + ud * ud + vd * vd;
         }
-        const float powden = fpow(pix.w, dpow);
+        const float powden = de_pow(pix.w, dpow);
         const float dfact = fexp2(dscale * fabsf(cpowden - powden));
         const float avg = blur[shear_idx(d, pat, xi, yi, (float)r)];
         float gradfact = fdiv(next.w - prev, avg + 1.0e-6f);
@@ -378,7 +378,7 @@ k_de_bilateral_pk(fl_dim d, float4 *__restrict__ Nout, float2 *__restrict__ PRou
         if (xo < 0 || xo >= (int)d.astride) continue;        // the parallelogram sticks out of the image at both ends of a band
         const uint32_t go = (uint32_t)((by0 + oy) * (int)d.astride + xo);
         Nout[go] = make_float4(sx * rn, sy * rn, sz * rn, wn);
-        PRout[go].x = fpow(wn, dpow);
+        PRout[go].x = de_pow(wn, dpow);
         Wout[go] = wn;
     }
 }
@@ -391,7 +391,7 @@ k_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float *__r
     const float4 p = src[gi];
     const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
-    PR[gi].x = fpow(p.w, dpow);
+    PR[gi].x = de_pow(p.w, dpow);
     W[gi] = p.w;
 }
 
@@ -492,7 +492,7 @@ k_yuv_de_prep2(fl_dim d, float4 *__restrict__ N, float2 *__restrict__ PR, float 
     const float4 p = yuv_px(src[gi]);
     const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
-    PR[gi].x = fpow(p.w, dpow);
+    PR[gi].x = de_pow(p.w, dpow);
     W[gi] = p.w;
 }
 //   DE finish [-> logscale] [-> colorclip] in one pass

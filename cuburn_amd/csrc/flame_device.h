@@ -64,6 +64,10 @@ __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * FM_LOG2E); }
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718246460f; }
 __device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+// density^dpow of the DE filter (cuburn/code/filters.py:204,233).  powf(0, 0) is 1; the reference's fast-math
+// powf (exp2f(y * __log2f(x))) and fpow give 0 * -inf = NaN there, i.e. a density power of exactly 0 breaks the
+// reference wherever a pixel is empty.  Here the exponent 0 (kernel-uniform) means what it says: w^0 = 1.
+__device__ __forceinline__ float de_pow(float w, float dpow) { return dpow == 0.0f ? 1.0f : fpow(w, dpow); }
 __device__ __forceinline__ float fsqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 // v_sin/v_cos take revolutions; v_fract keeps the argument in the instruction's valid domain
 __device__ __forceinline__ float fsin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189532f)); }

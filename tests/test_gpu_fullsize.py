@@ -69,6 +69,27 @@ def check_against_cpu_game(gnm, prof, tc, nslots, dim, front, nrun, ncpu, bs, l1
     return l1, noise, fg, fr
 
 
+# Bars of the full-size filter chain (tone-mapped values in [0, 1]).  Measured on cfg2 / cfg3 at 1080p and on the
+# 4K / 8K windows (tools/diag_chain_error.py, gpurun_out/fullsize_chain_errors.txt): the maximum sits at
+# single-hit pixels at the rim of the flame, where the colorclip's linear segment below `gamma_threshold`
+# multiplies differences by lin^(gamma - 1) = 31.6; above a DE density of 10 the relative error of the DE output
+# itself is a few 1e-6.  The bar is 10x the worst measured value, not SURVEY 8c's blanket 1e-3.
+CHAIN_MAX, CHAIN_P999, CHAIN_MEAN = 5e-4, 2e-5, 2e-6
+
+
+def check_chain_error(err, what):
+    stats = (float(err.max()), float(np.percentile(err, 99.9)), float(err.mean()))
+    try:
+        import os
+        if os.path.isdir('gpurun_out'):
+            with open('gpurun_out/fullsize_chain_errors.txt', 'a') as fp:
+                fp.write('%s: max %.3e p99.9 %.3e mean %.3e\n' % ((what,) + stats))
+    except OSError:
+        pass
+    assert stats[0] < CHAIN_MAX and stats[1] < CHAIN_P999 and stats[2] < CHAIN_MEAN, (what,) + stats
+    return stats
+
+
 def filter_chain_on_device(m, rdr, gprof, dim, tc):
     vals = {}
     for filt in rdr.filts:
@@ -98,9 +119,8 @@ def check_window(dim, accum, dev, vals, x0, y0, AW, AH, margin):
     ref = oracle_chain(d, acc2, vals).reshape(AH, AW, 4)[margin:AH - margin, margin:AW - margin]
     got = dev.reshape(dim.ah, dim.astride, 4)[y0 + margin:y0 + AH - margin, x0 + margin:x0 + AW - margin]
     err = np.abs(got - ref)
-    assert err.max() < 2e-2 and err.mean() < 2e-4 and np.percentile(err, 99.9) < 2e-3, (err.max(), err.mean())
     assert ref[..., 3].max() > 0.2, 'the window must contain part of the flame'
-    return err.max()
+    return check_chain_error(err, 'window %dx%d at (%d, %d) of %dx%d' % (AW, AH, x0, y0, dim.w, dim.h))[0]
 
 
 def densest_window(dim, accum, AW, AH):
@@ -124,8 +144,7 @@ def test_cfg3_full_size(built):
     vals, dev = filter_chain_on_device(m, rdr, gprof, dim, 0.37)
     d = O.calc_dim(gprof.width, gprof.height)
     ref = oracle_chain(d, front, vals)
-    err = np.abs(dev - ref)
-    assert err.max() < 2e-2 and err.mean() < 2e-4 and np.percentile(err, 99.9) < 2e-3, (err.max(), err.mean())
+    check_chain_error(np.abs(dev - ref), 'cfg3 whole frame')
     m.fb.free()
 
 

@@ -624,6 +624,37 @@ def test_filter_bilateral_narrow_colour_kernel(mgr, cstd):
     assert (err > tol).mean() < 2e-4, ((err > tol).mean(), err.max())
 
 
+# All 31 taps carry weight here (at sstd = 6 * 200 / 1920 the spatial coefficient is 4e-5 at r = 3 and below
+# 1e-8 from r = 4: the tests above exercise +-3 taps).  With sstd 6 / 12 / 24 — what 1080p / 4K / 8K frames
+# pass to the kernel — spa_coefs[15] = exp(-225 / (sqrt2 * sstd)) = 3e-12 / 1.8e-6 / 1.3e-3: the outer taps, the
+# +-16 prefetch and the half-slope rounding at large |r| all matter.  Also negative gradient speeds and the ends of
+# the density-power range.
+#   * dpow = 0: powf(0, 0) = 1 in the oracle (C).  The reference's fast-math powf = exp2f(0 * -inf) = NaN at every
+#     empty pixel, i.e. the reference is broken there; the device defines w^0 = 1 (flame_device.h de_pow).
+#   * dpow = 2 is ill-conditioned at high density whatever the implementation: the density factor is
+#     exp2(-0.5 / dstd * |w_c^2 - w_q^2|), and at w = 2000 one float32 ulp of w^2 (0.25 .. 0.5) moves the exponent by
+#     0.1, the tap weight by 7 % — the hardware pow (exp2(y * log2 x), ~10 ulp there; CUDA's __powf likewise) and
+#     glibc's powf then legitimately differ by 10 % in the output.  The dense buffer is therefore scaled to
+#     densities <= 40 for dpow = 2 (ulp(w^2) <= 1.2e-4); the default dpow = 0.8 is benign up to w ~ 1e6.
+WIDE_DE = [(6.0, 0.05, 1.5, 0.8, 4.0), (12.0, 0.05, 1.5, 0.8, 4.0), (24.0, 0.05, 1.5, 0.8, 4.0),
+           (24.0, 0.05, 1.5, 0.8, -3.0), (12.0, 0.1, 0.7, 0.0, 4.0), (12.0, 0.05, 3.0, 2.0, 1.0),
+           (24.0, 0.02, 1.5, 0.0, -6.0), (6.0, 0.05, 1.5, 2.0, 8.0)]
+
+
+@pytest.mark.parametrize('kind', ['dense', 'sparse'])
+@pytest.mark.parametrize('vals', WIDE_DE)
+def test_filter_bilateral_wide_parameters(mgr, kind, vals):
+    dim = mgr.fb.calc_dim(FW, FH); d = O.calc_dim(FW, FH)
+    buf = O.yuv_to_rgb(d, synth_accum(dim, seed=11)) if kind == 'dense' else sparse_accum(dim, seed=13)
+    vals = list(vals)
+    if vals[3] == 2.0:
+        buf = buf * np.float32(40.0 / buf[:, 3].max())
+    dev = run_filter(mgr, 'bilateral', dim, buf, vals)
+    ref = O.bilateral_chain(d, buf, *vals)
+    assert np.isfinite(ref).all()
+    assert_close(dev, ref, 2e-3, 2e-4, 'bilateral chain %s %r' % (kind, vals))
+
+
 def sparse_accum(dim, seed=3):
     """A few-samples-per-pixel buffer: isolated single hits, empty gaps, black and saturated colours
     (the regime where the DE weights underflow to denormals)."""
@@ -661,6 +692,36 @@ def test_filter_bilateral_sparse(built, form, monkeypatch):
     # energy is conserved up to the filter's own normalisation: no NaN/Inf swallowed by later clamps
     assert abs(dev[:, 3].sum() - ref[:, 3].sum()) < 1e-3 * ref[:, 3].sum()
     m.fb.free()
+
+
+@pytest.mark.parametrize('size,seg_rows', [((200, 120), None), ((200, 120), 32), ((200, 120), 33), ((200, 120), 70), ((200, 120), 500),
+                                           ((640, 360), None), ((1000, 999), None), ((1000, 999), 97), ((33, 31), None)])
+def test_de_band_equals_tiles(built, size, seg_rows, monkeypatch):
+    """The alternative form of directions 1..7 (FLAME_DE_BAND=1, de.hip k_de_band: sheared column bands that wrap
+    around the image, a rolling LDS window, every row staged once) against the default (k_de_dir: one 32 x 32 tile
+    with its halos per workgroup).  Same arithmetic in the same order: the whole chain must agree to the bit for any
+    segment length — one step, equal steps of 18..32 rows, segments shorter than a step, a single segment over the
+    whole image — on dense and on sparse input, incl. the image edges (direct evaluation of the blurs at clamped
+    positions, columns in the wrap gap)."""
+    w, h = size
+    outs = {}
+    for form in ('tiles', 'band'):
+        monkeypatch.delenv('FLAME_DE_BAND', raising=False)
+        monkeypatch.delenv('FLAME_DE_SEG_ROWS', raising=False)
+        if form == 'band':
+            monkeypatch.setenv('FLAME_DE_BAND', '1')
+            if seg_rows:
+                monkeypatch.setenv('FLAME_DE_SEG_ROWS', str(seg_rows))
+        m = render.RenderManager(device=0, nslots=NSLOTS, host_seed=7)
+        dim = m.fb.calc_dim(w, h); d = O.calc_dim(w, h)
+        res = []
+        for buf in (O.yuv_to_rgb(d, synth_accum(dim, seed=21)), sparse_accum(dim, seed=22)):
+            res.append(run_filter(m, 'bilateral', dim, buf, [6.0 * max(w, 640) / 1920., 0.05, 1.5, 0.8, 4.0]))
+        outs[form] = res
+        m.fb.free()
+    for a, b in zip(outs['tiles'], outs['band']):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (np.abs(a - b).max(), int((a != b).any(1).sum()))
 
 
 def test_filter_smearclip_chain(mgr):
@@ -1109,9 +1170,8 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     cur = O.colorclip(d, cur, *vals['colorclip'])
     assert np.isfinite(dev).all()
     # tone-mapped values live in [0, 1]: 8 DE passes + log + gamma in fast math on both sides
-    err = np.abs(dev - cur)
-    assert err.max() < 2e-2 and err.mean() < 2e-4, (err.max(), err.mean())
-    assert np.percentile(err, 99.9) < 2e-3, np.percentile(err, 99.9)
+    from test_gpu_fullsize import check_chain_error
+    check_chain_error(np.abs(dev - cur), 'cfg2 whole frame')
     m.fb.free()
 
 

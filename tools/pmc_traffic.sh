@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 tag=$1
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_${tag}_$ctr -o b -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 $BENCH_ARGS > gpurun_out/pmc_${tag}_$ctr.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_${tag}_$ctr -o b -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --min-timed-frames 0 $BENCH_ARGS > gpurun_out/pmc_${tag}_$ctr.log 2>&1
 done
 python3 - <<PY
 import csv, collections, json
