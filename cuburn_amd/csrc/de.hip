@@ -10,7 +10,7 @@
 //     right, K/2 being the direction's x step per row, so that every tap of a pixel, every tap of
 //     the two density blurs at a tap, and their neighbours land in (almost) the same COLUMN of the
 //     staged parallelogram: the halo is 24 rows (13 for the directions that advance two pixels per
-//     row) by 0..2 columns.  The horizontal direction uses 8 x 128 tiles with a 24-column halo.
+//     row) by 0..2 columns.  The horizontal direction uses 8 x 64 tiles with a 24-column halo.
 //   * Both density blurs (7 taps at step 1, 7 taps at step 2) are evaluated in LDS for every staged
 //     position a tap can reach, in the reference's summation order.
 //   * The gradient factor exp2(-exp2(+-gspeed * (next.w - prev.w) / (avg + 1e-6))) of a tap
@@ -21,8 +21,11 @@
 //     rounded), so the inner exponential stays in the loop (two v_exp_f32 per tap).
 //   * w^dpow is computed when a pixel is staged (2 transcendentals per staged pixel instead of a
 //     4-byte plane read and written per direction).
-//   * The kernel is VALU-bound (SQ counters: vector ALU busy > 80 %, ~4.3 cycles per wave
-//     instruction), so the tap arithmetic is arranged for the fewest instructions.  The colour
+//   * What bounds it (round 3, tools/valu_bench.hip wall-clock + tools/de_phases.py): a workgroup's life is a staging
+//     phase that mostly waits (global loads, barriers: 2.6-4.6 us) and a tap phase that computes (the taps of all
+//     resident workgroups together run the vector ALU at ~80 % of its measured peak of one wave instruction per
+//     1.21 ns per SIMD); a kernel then pays ~8-10 us of ramp-up and tail on top (every workgroup stages at the start,
+//     few are left at the end).  The tap arithmetic is arranged for the fewest instructions.  The colour
 //     distance |n_q - c|^2 is expanded: cs*|n_q|^2 is a per-pixel plane S, -2*cs*c a per-centre
 //     vector C', and cs*|c|^2 — common to every tap of a centre — is factored out of the loop
 //     altogether (all five sums scale by 2^(cs*|c|^2), which is undone once at the end):
@@ -36,7 +39,7 @@
 //
 // Scalar (non-packed) math: on gfx950 v_pk_fma_f32 issues at ~1.6x the cost of v_fma_f32
 // (tools/valu_bench.hip), which does not pay for the 16-apart pixel pairing and ds_read2_b32
-// traffic the packed form needs; 1024-thread workgroups at <= 64 VGPRs keep 8 waves per SIMD.
+// traffic the packed form needs; at <= 64 VGPRs a CU holds 32 waves (in workgroups of 256 or 512 threads, see DE_TW_).
 #include "flame_device.h"
 #include "kernels.h"
 #include "tone_device.h"
@@ -45,7 +48,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-struct DeCoefs { float k[7]; };
+struct DeCoefs { float k[7]; float k2[19]; };      // the blur's 7 taps; both blurs as ONE 19-tap kernel (integer-step directions)
 struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
 
 // ---- compile-time geometry of a direction --------------------------------------------------
@@ -69,8 +72,34 @@ __host__ __device__ constexpr int de_dv(int P, int par, int dx, int dy)
 }
 __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // integer steps: H+ / H- planes
 
+// Tile shapes (output pixels = threads of a workgroup).  Round 2 used 32 x 32 (8 x 128 for the horizontal
+// direction): two 1024-thread workgroups per CU.  A workgroup alternates a staging phase that mostly WAITS
+// (global loads, four barriers) and a tap phase that computes, and a CU holds 32 waves whatever their grouping:
+// smaller workgroups put more independent phases on a CU (512 threads: four per CU; 256: eight), and the
+// kernels are 10-18 % faster (profiles/r03_de_tile_shapes.txt).  Taller tiles (less halo) are slower.
 #ifndef DE_TW_
-#define DE_TW_ 32      /* 16 (64-row tiles, staged / output 1.75 instead of 2.5) measured 10-25 % slower: ragged band ends, 256-byte row segments */
+#define DE_TW_ 16      /* directions 4..7 (half slopes): 32 rows x 16 columns, 512 threads */
+#endif
+#ifndef DE_TH_
+#define DE_TH_ 32
+#endif
+#ifndef DE_TWH_
+#define DE_TWH_ 8      /* directions 1..3 (integer steps, no column halo): 32 x 8, 256 threads */
+#endif
+#ifndef DE_THH_
+#define DE_THH_ 32
+#endif
+#ifndef DE_TW0_
+#define DE_TW0_ 64     /* the horizontal direction: DE_TH0_ x DE_TW0_ tiles (round 2: 8 x 128) */
+#endif
+#ifndef DE_TH0_
+#define DE_TH0_ 8
+#endif
+#ifndef DE_PRIO_STAGE
+#define DE_PRIO_STAGE 3
+#endif
+#ifndef DE_FAST_PREP
+#define DE_FAST_PREP 1
 #endif
 struct DeReach { int hu, hv; };
 // Largest row / column displacement (sheared coordinates) of any staged value a tile pixel needs:
@@ -98,19 +127,28 @@ __host__ __device__ constexpr DeReach de_reach(int P, bool blur)
 
 template <int P> struct DeGeo {
     static constexpr int K = de_k(P);
-    // output tile (1024 pixels)
-    static constexpr int TW = P == 0 ? 128 : DE_TW_, TH = P == 0 ? 8 : 1024 / DE_TW_;
+    // output tile
+    static constexpr int TW = P == 0 ? DE_TW0_ : (de_hoisted(P) ? DE_TWH_ : DE_TW_);
+    static constexpr int TH = P == 0 ? DE_TH0_ : (de_hoisted(P) ? DE_THH_ : DE_TH_);
+    static constexpr int NT = TW * TH;                  // threads of a workgroup = output pixels of a tile
+    static_assert(NT % 64 == 0 && NT <= 1024 && (P == 0 ? TW % 64 == 0 : 64 % TW == 0 && TH % (128 / TW) == 0), "whole waves, rows of equal parity per wave");
     static constexpr bool HOIST = de_hoisted(P);
-    // plane A (normalised pixels): everything a tile pixel's taps and their blurs can reach
+    // staged region (densities): everything a tile pixel's taps and their blurs can reach
     static constexpr int HU = de_reach(P, true).hu, HV = de_reach(P, true).hv;
     static constexpr int ROWS = TH + 2 * HU, COLS = TW + 2 * HV, NPX = ROWS * COLS;
-    static constexpr int NIT = (NPX + 1023) / 1024;
+    static constexpr int NIT = (NPX + NT - 1) / NT;
+    // plane A (normalised pixels) holds only the rows the taps themselves read (r = -16 .. 16), with the staged
+    // region's columns: the outer rows are needed as densities for the blurs, not as pixels
+    static constexpr int HA = de_dy(P, 16) < 0 ? -de_dy(P, 16) : de_dy(P, 16);
+    static constexpr int AROWS = TH + 2 * HA, NPXA = AROWS * COLS, AOFF = (HU - HA) * COLS;      // A element = staged element - AOFF
+    static_assert(HA <= HU, "the taps reach no further than the blurs");
     // plane B (per-pixel tap terms): the positions of the taps themselves
     static constexpr int HBU = de_reach(P, false).hu, HBV = de_reach(P, false).hv;
     static constexpr int BROWS = TH + 2 * HBU, BCOLS = TW + 2 * HBV, NPXB = BROWS * BCOLS;
-    static constexpr int NITB = (NPXB + 1023) / 1024;
-    // LDS: A float4[NPX] | B float4[NPXB]; the preparation's two dense float planes live in B's space
-    static constexpr size_t LDS = (size_t)(NPX + NPXB) * 16 + 64;
+    static constexpr int NITB = (NPXB + NT - 1) / NT;
+    // LDS: A float4[NPXA] | B float4[NPXB] | (integer-step directions) the fast path's density plane float[NPX];
+    // the nested preparation's two dense float planes live in B's space
+    static constexpr size_t LDS = (size_t)(NPXA + NPXB) * 16 + (de_hoisted(P) ? (size_t)NPX * 4 : 0) + 64;
     static constexpr int SPAN = de_shear(P, TH - 1) < 0 ? -de_shear(P, TH - 1) : de_shear(P, TH - 1);
     // element offset of image displacement (dx, dy) from a position in a row of parity par
     static constexpr int off(int par, int dx, int dy) { return dy * COLS + de_dv(P, par, dx, dy); }
@@ -148,8 +186,10 @@ __device__ float de_b1_global(const float4 *__restrict__ N, const fl_dim &d, int
 template <int P>
 __device__ float de_b2_global(const float4 *__restrict__ N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
 {
+    // all 49 loads are issued before the first is waited for: as a loop of seven dependent rounds this was seven
+    // memory round trips (5-7 us) for the one tile that needs it, with the rest of its workgroup at the barrier
     float den = 0.0f;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int x = de_clampi(cx + de_dx(P, 2 * (i - 3)), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, 2 * (i - 3)), 0, (int)d.ah - 1);
         den += de_b1_global<P>(N, d, x, y, k) * k.k[i];
@@ -303,8 +343,27 @@ __device__ __forceinline__ float4 de_in_px(float4 p)
     return make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
 }
 
+// -DDE_X_PHASES: every workgroup adds the 100 MHz ticks it spent in each phase to de_phase_ticks[direction][phase]
+// (0 = until the loads are in LDS, 1 = first blur, 2 = tap terms, 3 = plane B written, 4 = taps + store, 5 = workgroups);
+// fl_debug_de_phases reads and clears them (tools/de_phases.py).
+#ifdef DE_X_PHASES
+#define DE_PH_MAXWG 16384
+__device__ unsigned long long de_phase_rec[8][DE_PH_MAXWG][6];      // per workgroup: no two writers share a word
+#define DE_PHASE(n) do { if (threadIdx.x == 0 && blockIdx.x < DE_PH_MAXWG) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); de_phase_rec[P][blockIdx.x][n] += now_ - tick_; tick_ = now_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int fl_debug_de_phases(unsigned long long *out, int clear)
+{
+    static unsigned long long host[8][DE_PH_MAXWG][6];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(de_phase_rec), sizeof host) != hipSuccess) return -1;
+    for (int p = 0; p < 8; ++p) for (int n = 0; n < 6; ++n) { unsigned long long a = 0; for (int w = 0; w < DE_PH_MAXWG; ++w) a += host[p][w][n]; out[p * 6 + n] = a; }
+    if (clear) { if (hipMemset(nullptr, 0, 0) != hipSuccess) (void)hipGetLastError(); void *sym = nullptr; if (hipGetSymbolAddress(&sym, HIP_SYMBOL(de_phase_rec)) != hipSuccess || hipMemset(sym, 0, sizeof host) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define DE_PHASE(n)
+#endif
+
 template <int P, int IN, int OUT>
-__global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
+__global__ void __launch_bounds__(DeGeo<P>::NT, 8)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
 k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
          float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
 {
@@ -312,15 +371,18 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *sA = reinterpret_cast<float4 *>(smem);
-    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPX * 16);
-    float *sW = reinterpret_cast<float *>(sB);                   // prep: dense density plane ...
+    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPXA * 16);
+    float *sW = reinterpret_cast<float *>(sB);                   // nested prep: dense density plane ...
     float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
+    float *sWf = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16);      // fast prep: density plane beside B
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles in column-major order, so that the tiles resident together on an XCD are vertical
     // neighbours and find each other's halo rows in that XCD's L2.
-    const uint32_t per_xcd = (ntiles + 7u) / 8u;
-    const uint32_t t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    // Tiles at the image's sides are the slow ones (staged positions outside the image evaluate their blurs on
+    // the global image): XCDs 4..7 walk their run backwards, so that the right edge is done first, not last.
+    const uint32_t per_xcd = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u;
+    const uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
     if (t >= ntiles) return;
     const int tx = (int)(t / tiles_y), ty = (int)(t % tiles_y);
     // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
@@ -332,11 +394,73 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
                         bx0 + min(0, de_shear(P, -G::HU)) + min(0, de_shear(P, G::TH + G::HU)) - G::HV - 1 < 0 ||
                         bx0 + max(0, de_shear(P, -G::HU)) + max(0, de_shear(P, G::TH + G::HU)) + G::TW + G::HV + 1 > (int)d.astride;
 
+    // Timing builds (results are garbage): -DDE_X_TAPSONLY runs the taps on whatever the LDS holds, -DDE_X_STOP_AFTER=n
+    // ends the workgroup after staging phase n (1..4) — tools/ab_de.sh, profiles/r03_de_phases.txt.
+    // Staging is a few instructions between long waits (global loads, barriers), the taps are 550 instructions
+    // back to back: with the arbiter's default order a young workgroup's staging instructions queue behind the
+    // older workgroups' tap loops and its loads go out late.  Staging therefore runs at raised priority, the
+    // taps at the default: the loads of the next tiles are in flight while the current tiles compute.
+    __builtin_amdgcn_s_setprio(DE_PRIO_STAGE);
+#ifdef DE_X_PHASES
+    unsigned long long tick_ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < DE_PH_MAXWG) de_phase_rec[P][blockIdx.x][5] += 1ull;
+#endif
+#ifdef DE_X_TAPSONLY
+    if (gspeed != 12345.0f) goto taps;
+#endif
+#ifdef DE_X_STOP_AFTER
+#define DE_X_STOP(n) if (DE_X_STOP_AFTER == n && gspeed != 12345.0f) { if (tid == 0 && sB[17].x == 1.2345e-33f) Nout[0] = sB[17]; return; }
+#else
+#define DE_X_STOP(n)
+#endif
+    // ---- integer-step directions, no staged position outside the image: two phases instead of four -----------
+    // The density blurs collapse into one 19-tap kernel on the staged densities (kc.k2), so the first blur's plane,
+    // its phase and its barrier go, and plane B can be written as it is computed (nothing aliases it): load ->
+    // barrier -> tap terms -> barrier.  The regrouped sum differs from the nested one by float rounding only (1e-7
+    // relative in `avg`); tiles that touch an image edge keep the nested form below, which follows the reference's
+    // clamped fetches literally.
+    if (G::HOIST && !border && DE_FAST_PREP) {
+        float4 tq[G::NIT];
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int idx = min(it * G::NT + tid, G::NPX - 1);
+            const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
+            const int gx = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gy = by0 + ul - G::HU;      // inside the image: no clamps
+            tq[it] = de_in_px<IN>(N[(uint32_t)(gy * (int)d.astride + gx)]);
+        }
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int idx = it * G::NT + tid;
+            if (idx < G::NPX) {
+                sWf[idx] = tq[it].w;
+                if (idx >= G::AOFF && idx < G::AOFF + G::NPXA) sA[idx - G::AOFF] = tq[it];
+            }
+        }
+        __syncthreads();
+        DE_PHASE(0);
+#pragma unroll
+        for (int it = 0; it < G::NITB; ++it) {
+            const int bidx = it * G::NT + tid;
+            if (bidx >= G::NPXB) continue;
+            const int ub = bidx / G::BCOLS, vb = bidx - ub * G::BCOLS;
+            const int idx = (ub + G::HU - G::HBU) * G::COLS + vb + G::HV - G::HBV;
+            float den = 0.0f;
+#pragma unroll
+            for (int m = -9; m <= 9; ++m) den = fmaf(sWf[idx + G::off(0, de_dx(P, m), de_dy(P, m))], kc.k2[m + 9], den);
+            const float ra = frcp(den + 1.0e-6f) * gspeed;
+            const float4 n = sA[idx - G::AOFF];
+            constexpr int dn = G::off(0, de_dx(P, 1), de_dy(P, 1));
+            const float g = (sWf[idx + dn] - sWf[idx - dn]) * ra;
+            sB[bidx] = make_float4(ads * de_pow(n.w, dpow), cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x)), fexp2(g), fexp2(-g));
+        }
+        __syncthreads();
+        DE_PHASE(2);
+    } else {
     // ---- S0: stage N (edge-clamped) and the dense density plane ------------------------------
     float4 tn[G::NIT];
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
-        const int idx = min(it * 1024 + tid, G::NPX - 1);
+        const int idx = min(it * G::NT + tid, G::NPX - 1);
         const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
         const int gx = de_clampi(bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, 0, xmax);
         const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
@@ -344,10 +468,15 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     }
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
-        const int idx = it * 1024 + tid;
-        if (idx < G::NPX) { sA[idx] = tn[it]; sW[idx] = tn[it].w; }
+        const int idx = it * G::NT + tid;
+        if (idx < G::NPX) {
+            sW[idx] = tn[it].w;
+            if (idx >= G::AOFF && idx < G::AOFF + G::NPXA) sA[idx - G::AOFF] = tn[it];
+        }
     }
     __syncthreads();
+    DE_X_STOP(1)
+    DE_PHASE(0);
 
     // ---- S1: first density blur (7 taps, step 1) ----------------------------------------------
     // Every staged position is evaluated; where a tap leaves the staged region it reads whatever
@@ -355,7 +484,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     // the value is meaningless — by construction of the halo (de_reach) no tile pixel ever needs it.
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
-        const int idx = it * 1024 + tid;
+        const int idx = it * G::NT + tid;
         if (idx >= G::NPX) continue;
         const int ul = idx / G::COLS, vl = idx - ul * G::COLS;
         const bool par = ((ul - G::HU) & 1) != 0;
@@ -374,6 +503,8 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         s1[idx] = den;
     }
     __syncthreads();
+    DE_X_STOP(2)
+    DE_PHASE(1);
 
     // ---- S2: per-pixel tap terms for every position a tap can land on -------------------------
     // second blur (7 taps, step 2) -> gspeed / (avg + 1e-6) -> gradient exponentials; |ds| * w^dpow;
@@ -381,7 +512,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     float4 pb[G::NITB];
 #pragma unroll
     for (int it = 0; it < G::NITB; ++it) {
-        const int bidx = it * 1024 + tid;
+        const int bidx = it * G::NT + tid;
         pb[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (bidx >= G::NPXB) continue;
         const int ub = bidx / G::BCOLS, vb = bidx - ub * G::BCOLS;
@@ -401,7 +532,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
                 den = de_b2_global<P>(N, d, de_clampi(gxu, 0, xmax), de_clampi(gyu, 0, ymax), kc);
         }
         const float ra = frcp(den + 1.0e-6f) * gspeed;
-        const float4 n = sA[idx];
+        const float4 n = sA[idx - G::AOFF];
         pb[it].x = ads * de_pow(n.w, dpow);
         pb[it].y = cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x));
         if (G::HOIST) {
@@ -417,25 +548,34 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         }
     }
     __syncthreads();
+    DE_X_STOP(3)
+    DE_PHASE(2);
     // ---- S3: the per-pixel plane replaces the preparation planes -------------------------------
 #pragma unroll
     for (int it = 0; it < G::NITB; ++it) {
-        const int bidx = it * 1024 + tid;
+        const int bidx = it * G::NT + tid;
         if (bidx < G::NPXB) sB[bidx] = pb[it];
     }
     __syncthreads();
+    DE_X_STOP(4)
+    DE_PHASE(3);
 
+    }
+#ifdef DE_X_TAPSONLY
+taps:
+#endif
+    __builtin_amdgcn_s_setprio(0);
     // ---- taps --------------------------------------------------------------------------------
     // thread -> output pixel: a wave covers two rows of equal parity (row parity selects the tap
     // offsets when K is odd); the horizontal direction: 64 consecutive pixels of one row
     const int wv = tid >> 6, lane = tid & 63;
     int ou, ov;
-    if (P == 0) { ou = wv >> 1; ov = (wv & 1) * 64 + lane; }
+    if (P == 0) { constexpr int WPR = G::TW / 64; ou = wv / WPR; ov = (wv % WPR) * 64 + lane; }
     else {
         constexpr int RPW = 64 / G::TW;                                   // rows per wave (equal parity)
         ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW); ov = lane % G::TW;
     }
-    const int ci = (ou + G::HU) * G::COLS + ov + G::HV;
+    const int ci = (ou + G::HA) * G::COLS + ov + G::HV;
     const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
     float4 res;
     if ((G::K & 1) && (wv & 1)) de_tap_loop<P, 1>(sA, sB, ci, cb, cs2, spk, res);
@@ -451,274 +591,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         }
         Nout[(uint32_t)(yo * (int)d.astride + xo)] = res;
     }
-}
-
-// ---- band walker ------------------------------------------------------------------------------------
-// k_de_dir stages a 32-row tile with its 24-row halos for every 32 rows of output: 2.5 staged pixels per
-// output pixel, each with its two blur values, w^dpow, two exponentials — 205 of the kernel's 763 issue
-// slots per pixel.  Here a workgroup owns a sheared column BAND over a SEGMENT of rows and walks down it,
-// keeping the staged window in LDS: after a step of `adv` rows the planes move up by `adv` rows (a block
-// move through registers, ~5 % of the LDS traffic of the step's taps) and only the new rows are loaded and
-// prepared — every row of a segment is staged once, plus the halos at the segment's ends.
-//   * The two dense preparation planes (density, first blur) live in the space of plane B's new rows, which
-//     is free until those rows are written.
-//   * Steps have equal height: adv = rows of the segment / steps, rounded up to an even number (<= TH): a
-//     last step of 10 rows costs what a step of 32 costs (measured), 5 steps of 28 cost 5 x 28.
-//   * Bands wrap around the image: column x of a sheared band is taken modulo W = bands x TW, so every band
-//     is full over all its rows and the workgroup count is bands x segments <= two per CU — all resident
-//     at once, equal work, no second round for the bands that would stick out of the image.  W exceeds the
-//     image width by more than twice the reach of any staged position beyond an image edge, so a wrapped
-//     column outside the image is either "right of the right edge" or "left of the left edge" (nearer gap
-//     end), which is all the reference's clamped fetches need.
-// Same LDS layout, same tap loop, same arithmetic in the same order as k_de_dir: bit-identical results
-// (test_de_band_equals_tiles).
-template <int P> struct DeBand {
-    using G = DeGeo<P>;
-    static constexpr int RB1 = de_dy(P, 3) < 0 ? -de_dy(P, 3) : de_dy(P, 3);      // rows reached by the first blur
-    static constexpr int RB2 = de_dy(P, 6) < 0 ? -de_dy(P, 6) : de_dy(P, 6);      // ... by the second
-    static constexpr int LA = G::HU - G::HBU;                                     // both: what a B row needs beyond itself
-    static_assert(LA == RB1 + RB2, "halo of plane A = tap reach + both blurs");
-    // smallest step for which the preparation planes fit into the new rows of plane B
-    static constexpr int min_adv()
-    {
-        int a = 2;
-        while (2 * (a + 2 * LA) * G::COLS * 4 > a * G::BCOLS * 16) a += 2;
-        return a;
-    }
-    static constexpr int MIN_ADV = min_adv();
-    static_assert(MIN_ADV <= G::TH / 2 + 2, "two steps must be able to share a segment of TH + 1 rows");
-    // how far beyond an image edge (in x) a staged position that matters can lie: the taps' and blurs' reach
-    static constexpr int xreach()
-    {
-        int m = 0;
-        for (int r = -16; r <= 16; ++r) { const int a = de_dx(P, r) < 0 ? -de_dx(P, r) : de_dx(P, r); m = a > m ? a : m; }
-        const int b2 = de_dx(P, 6) < 0 ? -de_dx(P, 6) : de_dx(P, 6), b1 = de_dx(P, 3) < 0 ? -de_dx(P, 3) : de_dx(P, 3);
-        return m + b2 + b1 + G::HV + 2;
-    }
-    static constexpr int GAP = 2 * xreach() + 2;
-};
-
-struct DeBandPos { int bx0, yseg, wtot; };      // column 0 of the band at the segment's first row; that row; wrap width
-
-// wrapped image column of band column v (may be negative / beyond TW: halo) in the row `rel` rows below the segment's first
-template <int P>
-__device__ __forceinline__ int de_band_x(const DeBandPos &bp, int rel, int v)
-{
-    int x = (bp.bx0 + ((rel * DeGeo<P>::K) >> 1) + v) % bp.wtot;
-    return x < 0 ? x + bp.wtot : x;
-}
-// the pixel a wrapped column stands for when it lies in the gap: the nearer image edge
-__device__ __forceinline__ int de_band_clampx(const DeBandPos &bp, int xw, int xmax)
-{
-    return xw <= xmax ? xw : (xw - xmax <= bp.wtot - xw ? xmax : 0);
-}
-
-// edge-clamped load of plane A's element idx (rows counted from the plane's row ul0; rbase = rel of the plane's row 0)
-template <int P>
-__device__ __forceinline__ float4 de_band_load(const float4 *__restrict__ N, const fl_dim &d, int idx, int ul0, const DeBandPos &bp, int rbase)
-{
-    using G = DeGeo<P>;
-    const int ul = idx / G::COLS + ul0, vl = idx % G::COLS;
-    const int rel = rbase + ul;
-    const int gx = de_band_clampx(bp, de_band_x<P>(bp, rel, vl - G::HV), (int)d.astride - 1);
-    const int gy = de_clampi(bp.yseg + rel, 0, (int)d.ah - 1);
-    return N[(uint32_t)(gy * (int)d.astride + gx)];
-}
-
-// Prepare nb rows of plane B starting at its row ub0 (0, BROWS: the whole window; BROWS - adv, adv: the new rows
-// of a step).  rbase = row of plane A's row 0 relative to the segment's first row; rows_need: B rows beyond
-// this count (from ub0) are not needed by any output of the segment and are skipped.
-template <int P>
-__device__ __forceinline__ void de_band_prepare(const float4 *__restrict__ N, const fl_dim &d, float4 *sA, float4 *sB, int tid,
-                                                int ub0, int nb, const DeBandPos &bp, int rbase, int rows_need, const DeCoefs &kc,
-                                                float cs2, float ads, float dpow, float gspeed)
-{
-    using G = DeGeo<P>;
-    using Bd = DeBand<P>;
-    const int wrows = nb + 2 * Bd::LA, wpx = wrows * G::COLS;
-    float *sW = reinterpret_cast<float *>(sB + ub0 * G::BCOLS);          // dense density plane: rows ub0 .. ub0 + wrows of plane A
-    float *s1 = sW + wpx;                                                // first blur, same geometry
-    const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
-    const int wneed = (min(rows_need, nb) + 2 * Bd::LA) * G::COLS;       // temp-plane elements that matter
-    // does any position of these rows leave the image?  (block-uniform: rows, or columns that reach the gap)
-    const int rel0 = rbase + ub0, rel1 = rbase + ub0 + wrows - 1;
-    const int sh0 = (rel0 * G::K) >> 1, sh1 = (rel1 * G::K) >> 1;
-    bool border = bp.yseg + rel0 < 0 || bp.yseg + rel1 > ymax;
-    {
-        int lo = (bp.bx0 + min(sh0, sh1) - G::HV - 1) % bp.wtot;
-        lo = lo < 0 ? lo + bp.wtot : lo;
-        border = border || lo + (max(sh0, sh1) - min(sh0, sh1)) + G::TW + 2 * G::HV + 2 > xmax;
-    }
-    const float4 *sAw = sA + ub0 * G::COLS;
-
-    for (int idx = tid; idx < wneed; idx += 1024) sW[idx] = sAw[idx].w;
-    __syncthreads();
-    // first blur (7 taps, step 1), in the reference's summation order
-    for (int idx = tid; idx < wneed; idx += 1024) {
-        const int wl = idx / G::COLS, vl = idx - wl * G::COLS;
-        if (wl < Bd::RB1 || wl >= wrows - Bd::RB1) continue;
-        const int rel = rbase + ub0 + wl;
-        const bool par = (rel & 1) != 0;
-        float den = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int o0 = G::off(0, de_dx(P, j - 3), de_dy(P, j - 3)), o1 = G::off(1, de_dx(P, j - 3), de_dy(P, j - 3));
-            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
-            den = fmaf(sW[idx + o], kc.k[j], den);
-        }
-        if (border) {
-            const int gxw = de_band_x<P>(bp, rel, vl - G::HV), gyu = bp.yseg + rel;
-            if (gxw > xmax || gyu < 0 || gyu > ymax)                    // virtual position: the blur AT the clamped position
-                den = de_b1_global<P>(N, d, de_band_clampx(bp, gxw, xmax), de_clampi(gyu, 0, ymax), kc);
-        }
-        s1[idx] = den;
-    }
-    __syncthreads();
-    // per-pixel tap terms of the nb rows; held in registers until every thread is done with the planes
-    constexpr int NITB = (G::NPXB + 1023) / 1024;
-    const int nbpx = min(rows_need, nb) * G::BCOLS;
-    float4 pb[NITB];
-#pragma unroll
-    for (int it = 0; it < NITB; ++it) {
-        const int bidx = it * 1024 + tid;
-        pb[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (bidx >= nbpx) continue;
-        const int ubr = bidx / G::BCOLS, vb = bidx - ubr * G::BCOLS;          // row within the nb rows
-        const int wl = ubr + Bd::LA, vl = vb + G::HV - G::HBV;
-        const int idx = wl * G::COLS + vl;
-        const int rel = rbase + ub0 + wl;
-        const bool par = (rel & 1) != 0;
-        float den = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int o0 = G::off(0, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3))), o1 = G::off(1, de_dx(P, 2 * (i - 3)), de_dy(P, 2 * (i - 3)));
-            const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
-            den = fmaf(s1[idx + o], kc.k[i], den);
-        }
-        if (border) {
-            const int gxw = de_band_x<P>(bp, rel, vl - G::HV), gyu = bp.yseg + rel;
-            if (gxw > xmax || gyu < 0 || gyu > ymax)
-                den = de_b2_global<P>(N, d, de_band_clampx(bp, gxw, xmax), de_clampi(gyu, 0, ymax), kc);
-        }
-        const float ra = frcp(den + 1.0e-6f) * gspeed;
-        const float4 n = sAw[idx];
-        pb[it].x = ads * de_pow(n.w, dpow);
-        pb[it].y = cs2 * fmaf(n.z, n.z, fmaf(n.y, n.y, n.x * n.x));
-        if (G::HOIST) {
-            constexpr int dn = G::off(0, de_dx(P, 1), de_dy(P, 1));
-            const float g = (sW[idx + dn] - sW[idx - dn]) * ra;
-            pb[it].z = fexp2(g);
-            pb[it].w = fexp2(-g);
-        } else {
-            pb[it].z = ra;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NITB; ++it) {
-        const int bidx = it * 1024 + tid;
-        if (bidx < nb * G::BCOLS) sB[ub0 * G::BCOLS + bidx] = pb[it];
-    }
-    __syncthreads();
-}
-
-template <int P, int OUT>
-__global__ void __launch_bounds__(1024, 8)      // 8 waves per SIMD = two workgroups per CU
-k_de_band(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
-          float cs2, float ads, float dpow, float gspeed, uint32_t nbands, uint32_t nseg, uint32_t seg_rows, DeTail tail)
-{
-    using G = DeGeo<P>;
-    using Bd = DeBand<P>;
-    static_assert(P != 0, "the horizontal direction keeps its 8 x 128 tiles");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *sA = reinterpret_cast<float4 *>(smem);
-    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPX * 16);
-    const int tid = threadIdx.x;
-    const uint32_t seg = blockIdx.x % nseg, band = blockIdx.x / nseg;
-    DeBandPos bp;
-    bp.yseg = (int)(seg * seg_rows);
-    bp.bx0 = (int)band * G::TW;
-    bp.wtot = (int)nbands * G::TW;
-    const int rows_here = min((int)seg_rows, (int)d.ah - bp.yseg);
-    if (rows_here <= 0) return;
-    const int xmax = (int)d.astride - 1;
-    // equal steps: as few as fit (TH rows each at most), the same even number of rows in each
-    const int nsteps = (rows_here + G::TH - 1) / G::TH;
-    const int adv = nsteps == 1 ? G::TH : max(Bd::MIN_ADV, (((rows_here + nsteps - 1) / nsteps) + 1) & ~1);
-
-    // ---- the first window: all of plane A, all of plane B -----------------------------------------
-    for (int idx = tid; idx < G::NPX; idx += 1024) sA[idx] = de_band_load<P>(N, d, idx, 0, bp, -G::HU);
-    __syncthreads();
-    de_band_prepare<P>(N, d, sA, sB, tid, 0, G::BROWS, bp, -G::HU, rows_here + 2 * G::HBU, kc, cs2, ads, dpow, gspeed);
-
-    for (int s = 0;; ++s) {
-        // Everything a phase needs is derived from an opaque copy of the thread id inside the phase: nothing
-        // but the id itself is live across the tap loop, which owns the 64 registers (values the compiler would
-        // otherwise hoist out of this loop end up in scratch).
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        // ---- taps ------------------------------------------------------------------------------
-        // thread -> output pixel of a step (as k_de_dir): a wave covers rows of equal parity
-        const int wv = t >> 6, lane = t & 63;
-        constexpr int RPW = 64 / G::TW;
-        const int ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW), ov = lane % G::TW;
-        const int ci = (ou + G::HU) * G::COLS + ov + G::HV;
-        const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
-        const int rel = s * adv + ou;
-        const bool inside = ou < adv && rel < rows_here && de_band_x<P>(bp, rel, ov) <= xmax;
-        if (__ballot(inside) != 0ull) {                             // wave-uniform: rows past the step / segment, columns in the gap
-            float cs2l = cs2;
-            asm volatile("" : "+s"(cs2l));                          // (its multiples are recomputed per step, not kept in registers)
-            float4 res;
-            if ((G::K & 1) && (wv & 1)) de_tap_loop<P, 1>(sA, sB, ci, cb, cs2l, spk, res);
-            else de_tap_loop<P, 0>(sA, sB, ci, cb, cs2l, spk, res);
-            // the output position again, from the thread id
-            int t2 = tid;
-            asm volatile("" : "+v"(t2));
-            const int wv2 = t2 >> 6, lane2 = t2 & 63;
-            const int ou2 = (wv2 >> 1) * (2 * RPW) + (wv2 & 1) + 2 * (lane2 / G::TW);
-            const int rel2 = s * adv + ou2;
-            const int xo2 = de_band_x<P>(bp, rel2, lane2 % G::TW);
-            if (ou2 < adv && rel2 < rows_here && xo2 <= xmax) {
-                if (OUT) {                                          // as k_de_finish_tone (filters.hip)
-                    float4 p = make_float4(res.x * res.w, res.y * res.w, res.z * res.w, res.w);
-                    if (tail.do_log) p = logscale_px(p, tail.k1, tail.k2);
-                    if (tail.do_clip) p = colorclip_px(p, tail.vib, tail.highpow, tail.gam, tail.lin, tail.lingam);
-                    res = p;
-                }
-                Nout[(uint32_t)((bp.yseg + rel2) * (int)d.astride + xo2)] = res;
-            }
-        }
-        if ((s + 1) * adv >= rows_here) break;
-        int u = tid;
-        asm volatile("" : "+v"(u));
-        // ---- the window moves down by adv rows --------------------------------------------------------
-        const int rbase = (s + 1) * adv - G::HU;
-        // output rows from the next step on; as many of the adv new rows of either plane are needed by them
-        // (a new row of plane A / B lies HU / HBU rows below the step's first output row)
-        const int new_need = min(rows_here - (s + 1) * adv, adv);
-        const int keep_a = (G::ROWS - adv) * G::COLS, keep_b = (G::BROWS - adv) * G::BCOLS;
-        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        constexpr int NK = (G::NPX + 1023) / 1024;
-        static_assert(NK <= 3 && (G::NPXB + 1023) / 1024 <= 3, "three elements per thread at most");
-        const float4 na0 = u < new_need * G::COLS ? de_band_load<P>(N, d, u, G::ROWS - adv, bp, rbase) : zero;
-        const float4 na1 = u + 1024 < new_need * G::COLS ? de_band_load<P>(N, d, u + 1024, G::ROWS - adv, bp, rbase) : zero;
-        const float4 ka0 = sA[min(u, keep_a - 1) + adv * G::COLS], ka1 = sA[min(u + 1024, keep_a - 1) + adv * G::COLS],
-                     ka2 = sA[min(u + 2048, keep_a - 1) + adv * G::COLS];
-        const float4 kb0 = sB[min(u, keep_b - 1) + adv * G::BCOLS], kb1 = sB[min(u + 1024, keep_b - 1) + adv * G::BCOLS],
-                     kb2 = sB[min(u + 2048, keep_b - 1) + adv * G::BCOLS];
-        __syncthreads();
-        if (u < keep_a) sA[u] = ka0;
-        if (u + 1024 < keep_a) sA[u + 1024] = ka1;
-        if (u + 2048 < keep_a) sA[u + 2048] = ka2;
-        if (u < keep_b) sB[u] = kb0;
-        if (u + 1024 < keep_b) sB[u + 1024] = kb1;
-        if (u + 2048 < keep_b) sB[u + 2048] = kb2;
-        if (u < adv * G::COLS) sA[keep_a + u] = na0;
-        if (u + 1024 < adv * G::COLS) sA[keep_a + u + 1024] = na1;
-        __syncthreads();
-        de_band_prepare<P>(N, d, sA, sB, u, G::BROWS - adv, adv, bp, rbase, new_need, kc, cs2, ads, dpow, gspeed);
-    }
+    DE_PHASE(4);
 }
 
 template <bool YUV>
@@ -737,70 +610,36 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
                               float cs2, float ads, float dpow, float gspeed, DeTail tail)
 {
     using G = DeGeo<P>;
-    static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
+    static_assert(G::LDS * (2048 / G::NT) <= 160 * 1024, "LDS must allow 32 waves per CU");
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
+    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(G::NT), G::LDS, st, d, Nout, N, kc, spk,
                        cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
-}
-
-// Band walker: bands x segments <= two workgroups per CU (all resident at once, equal rows each);
-// seg_env > 0 (FLAME_DE_SEG_ROWS) sets the segment length (tests).
-template <int P, int OUT>
-static void launch_de_band_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
-                               float cs2, float ads, float dpow, float gspeed, DeTail tail, int seg_env)
-{
-    using G = DeGeo<P>;
-    using Bd = DeBand<P>;
-    static_assert(G::LDS <= 80 * 1024, "two workgroups per CU");
-    static unsigned long long attr = 0;
-    ensure_max_dynamic_lds((const void *)k_de_band<P, OUT>, attr);
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cus = 256; }
-        slots = 2 * cus;
-    }
-    const uint32_t nbands = (d.astride + (uint32_t)Bd::GAP + G::TW - 1) / G::TW;
-    uint32_t nseg = std::max(1u, std::min((uint32_t)slots / nbands, std::max(1u, d.ah / (uint32_t)G::TH)));
-    uint32_t seg_rows = (d.ah + nseg - 1) / nseg;
-    if (seg_env > 0) seg_rows = (uint32_t)seg_env;
-    nseg = (d.ah + seg_rows - 1) / seg_rows;
-    hipLaunchKernelGGL((k_de_band<P, OUT>), dim3(nbands * nseg), dim3(1024), G::LDS, st, d, Nout, N, kc, spk,
-                       cs2, ads, dpow, gspeed, nbands, nseg, seg_rows, tail);
 }
 
 // in_mode (pattern 0 only): 0 = N holds the normalised image, 1 = the raw accumulator, 2 = the raw YUV
 // accumulator.  tail (pattern 7 only, may be null): un-normalise + the tone filters riding along.
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail, int form)
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail)
 {
     DeCoefs kc;
     for (int i = 0; i < 7; ++i) kc.k[i] = coefs7[i];
+    // blur2(blur1(w))(q) = sum_i k_i sum_j k_j w(q + t(2i) + t(j)) = sum_m K_m w(q + t(m)), K_m = sum_{2i + j = m} k_i k_j,
+    // wherever t(a) + t(b) = t(a + b): the four directions with integer steps, away from the image edges
+    for (int m = -9; m <= 9; ++m) {
+        float a = 0.0f;
+        for (int i = -3; i <= 3; ++i) { const int j = m - 2 * i; if (j >= -3 && j <= 3) a += coefs7[i + 3] * coefs7[j + 3]; }
+        kc.k2[m + 9] = a;
+    }
     // per-launch scalars (cuburn/code/filters.py:176-183), evaluated once on the host
     DeSpatial spk;
     for (int r = 0; r < 16; ++r) spk.s[r] = expf((float)(r * r) / (-1.41421353816986f * sstd));
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
     const DeTail none = {};
-    const bool tiles = (form & 1) != 0;
-    const int seg_rows = form >> 8;
 #define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none)
-#define DB(P, O) launch_de_band_one<P, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none, seg_rows)
-    if (!tiles && pattern >= 1 && pattern <= 7) {
-        switch (pattern) {
-        case 1: DB(1, 0); break;
-        case 2: DB(2, 0); break;
-        case 3: DB(3, 0); break;
-        case 4: DB(4, 0); break;
-        case 5: DB(5, 0); break;
-        case 6: DB(6, 0); break;
-        default: if (tail) DB(7, 1); else DB(7, 0); break;
-        }
-        return;
-    }
     switch (pattern) {
     case 0: if (in_mode == 2) DE(0, 2, 0); else if (in_mode == 1) DE(0, 1, 0); else DE(0, 0, 0); break;
     case 1: DE(1, 0, 0); break;
@@ -813,7 +652,6 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     default: break;
     }
 #undef DE
-#undef DB
 }
 
 void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv)

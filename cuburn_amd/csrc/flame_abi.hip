@@ -92,8 +92,6 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    int de_dir_mask = 0xff;
-    int de_form = 0;                     // launch_de_dir's `form`: FLAME_DE_TILES, FLAME_DE_SEG_ROWS
     bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
 };
@@ -248,11 +246,6 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     c->env_de_unfused_ends = env_on("FLAME_DE_UNFUSED_ENDS");   // separate normalise / un-normalise passes around the 8 directions
-    // One kernel per direction, two forms: a workgroup per 32 x 32 tile (default) or the band walker of round 3
-    // (FLAME_DE_BAND=1: rolling LDS window, every row staged once; bit-identical, measured 10-20 % slower: DESIGN 4.3)
-    c->de_form = env_on("FLAME_DE_BAND") ? 0 : 1;
-    if (const char *e = getenv("FLAME_DE_SEG_ROWS")) { int v = atoi(e); if (v >= 1 && v < (1 << 20)) c->de_form |= v << 8; }
-    if (const char *e = getenv("FLAME_DE_DIR_MASK")) c->de_dir_mask = (int)strtol(e, nullptr, 0) & 0xff;
     c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
@@ -739,7 +732,7 @@ static void run_de_finish(fl_ctx *c, const float *clip)
         DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
                     clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
         launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, ln.pend_N, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
-                      ln.pend_dp[3], ln.pend_dp[4], 0, &t, c->de_form);
+                      ln.pend_dp[3], ln.pend_dp[4], 0, &t);
     } else
         launch_de_finish_tone(ln.stream, ln.pend_dim, ln.d_front, ln.pend_N, ln.pend_log, ln.pend_k1, ln.pend_k2, clip != nullptr, clip);
     ln.pend_finish = ln.pend_log = ln.pend_last = false;
@@ -792,8 +785,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
                 launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
                 L(c).pend_yuv = false;
                 for (int pat = 0; pat < 8; ++pat) {
-                    if (!(c->de_dir_mask >> pat & 1)) continue;          // FLAME_DE_DIR_MASK (debugging): a subset of the directions
-                    launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4], 0, nullptr, c->de_form);
+                    launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
                     std::swap(Na, Nb);
                 }
                 L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
@@ -805,7 +797,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
             launch_de_dir(st, d, 0, Na, Nb, k7, p[0], p[1], p[2], p[3], p[4], L(c).pend_yuv ? 2 : 1, nullptr);
             L(c).pend_yuv = false;
             for (int pat = 1; pat < 7; ++pat) {
-                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4], 0, nullptr, c->de_form);
+                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(Na, Nb);
             }
             // six swaps: the image sits in Na == d_back again

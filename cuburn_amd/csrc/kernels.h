@@ -91,8 +91,7 @@ void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 // tone filters that ride along with the last DE direction (filters.py default chains: DE -> logscale -> colorclip)
 struct DeTail { int do_log; float k1, k2; int do_clip; float vib, highpow, gam, lin, lingam; };
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 0, const DeTail *tail = nullptr,
-                   int form = 0);      // form: bit 0 = one workgroup per tile for every direction (round-2 form); bits 8.. = rows per band segment (0: automatic)
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 0, const DeTail *tail = nullptr);
 void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv);
 
 // output.hip

@@ -69,12 +69,13 @@ def check_against_cpu_game(gnm, prof, tc, nslots, dim, front, nrun, ncpu, bs, l1
     return l1, noise, fg, fr
 
 
-# Bars of the full-size filter chain (tone-mapped values in [0, 1]).  Measured on cfg2 / cfg3 at 1080p and on the
-# 4K / 8K windows (tools/diag_chain_error.py, gpurun_out/fullsize_chain_errors.txt): the maximum sits at
-# single-hit pixels at the rim of the flame, where the colorclip's linear segment below `gamma_threshold`
-# multiplies differences by lin^(gamma - 1) = 31.6; above a DE density of 10 the relative error of the DE output
-# itself is a few 1e-6.  The bar is 10x the worst measured value, not SURVEY 8c's blanket 1e-3.
-CHAIN_MAX, CHAIN_P999, CHAIN_MEAN = 5e-4, 2e-5, 2e-6
+# Bars of the full-size filter chain (tone-mapped values in [0, 1]).  Measured (gpurun_out/fullsize_chain_errors.txt,
+# tools/diag_chain_error.py): cfg2 / cfg3 whole 1080p frames max 2.2e-5 / 2.3e-5, 99.9 % below 1.2e-6, mean 4e-8; the
+# 4K / 8K windows max 1.7e-6 / 6.4e-6.  The maximum sits at single-hit pixels at the rim of the flame, where
+# colorclip's linear segment below `gamma_threshold` multiplies differences by lin^(gamma - 1) = 31.6; above a DE
+# density of 10 the relative error of the DE output itself is 3e-6.  The bars are ~4x the worst measured values
+# (round 2 asked for max < 2e-2): hardware exp / log / rcp on one side, libm on the other.
+CHAIN_MAX, CHAIN_P999, CHAIN_MEAN = 1e-4, 5e-6, 5e-7
 
 
 def check_chain_error(err, what):

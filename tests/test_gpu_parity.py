@@ -694,36 +694,6 @@ def test_filter_bilateral_sparse(built, form, monkeypatch):
     m.fb.free()
 
 
-@pytest.mark.parametrize('size,seg_rows', [((200, 120), None), ((200, 120), 32), ((200, 120), 33), ((200, 120), 70), ((200, 120), 500),
-                                           ((640, 360), None), ((1000, 999), None), ((1000, 999), 97), ((33, 31), None)])
-def test_de_band_equals_tiles(built, size, seg_rows, monkeypatch):
-    """The alternative form of directions 1..7 (FLAME_DE_BAND=1, de.hip k_de_band: sheared column bands that wrap
-    around the image, a rolling LDS window, every row staged once) against the default (k_de_dir: one 32 x 32 tile
-    with its halos per workgroup).  Same arithmetic in the same order: the whole chain must agree to the bit for any
-    segment length — one step, equal steps of 18..32 rows, segments shorter than a step, a single segment over the
-    whole image — on dense and on sparse input, incl. the image edges (direct evaluation of the blurs at clamped
-    positions, columns in the wrap gap)."""
-    w, h = size
-    outs = {}
-    for form in ('tiles', 'band'):
-        monkeypatch.delenv('FLAME_DE_BAND', raising=False)
-        monkeypatch.delenv('FLAME_DE_SEG_ROWS', raising=False)
-        if form == 'band':
-            monkeypatch.setenv('FLAME_DE_BAND', '1')
-            if seg_rows:
-                monkeypatch.setenv('FLAME_DE_SEG_ROWS', str(seg_rows))
-        m = render.RenderManager(device=0, nslots=NSLOTS, host_seed=7)
-        dim = m.fb.calc_dim(w, h); d = O.calc_dim(w, h)
-        res = []
-        for buf in (O.yuv_to_rgb(d, synth_accum(dim, seed=21)), sparse_accum(dim, seed=22)):
-            res.append(run_filter(m, 'bilateral', dim, buf, [6.0 * max(w, 640) / 1920., 0.05, 1.5, 0.8, 4.0]))
-        outs[form] = res
-        m.fb.free()
-    for a, b in zip(outs['tiles'], outs['band']):
-        assert np.isfinite(a).all()
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (np.abs(a - b).max(), int((a != b).any(1).sum()))
-
-
 def test_filter_smearclip_chain(mgr):
     dim = mgr.fb.calc_dim(FW, FH); d = O.calc_dim(FW, FH)
     buf = O.logscale(d, O.yuv_to_rgb(d, synth_accum(dim)), 4.1875, 0.02)
