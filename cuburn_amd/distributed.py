@@ -8,9 +8,14 @@ collective per round of frames (RCCL over xGMI when the backend is "nccl"; the s
 runs on "gloo" for the CPU tests).
 
 A single large frame can instead be sharded by SAMPLES: every rank iterates
-``nsamples/world`` samples with its own RNG streams into its own accumulator, the float4
-accumulators are summed with one all-reduce (the only exchange of the path: 16 B x nbins, e.g.
-537 MB at 8K, ~7 links x 153 GB/s of xGMI per GPU), and the filter chain runs on the sum.
+``nsamples/world`` samples with its own RNG streams into its own accumulator.  The float4
+accumulators are then summed BY ROW BANDS: a reduce-scatter leaves every rank with the sum of its
+own band of rows (16 B x nbins x (N-1)/N per rank over xGMI: half of what an all-reduce moves), the
+neighbours exchange ``BAND_HALO`` summed rows, every rank runs the filter chain on its band only
+(a band plus halos is an image of its own: the filters are local, and a halo wider than the chain's
+reach reproduces the interior exactly), and the finished 8-bit bands are all-gathered.  Without
+bands (``bands=False``, images too small for the halo, one rank) the accumulators are all-reduced
+and every rank filters the whole frame.
 """
 import ctypes as C
 
@@ -257,7 +262,99 @@ def accumulator_tensor(fb, device, dim=None):
     return torch.as_tensor(_DeviceArray(p.value, nfloats), device=torch.device('cuda', device))
 
 
-def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True):
+# Rows of summed accumulator a band carries beyond its own rows on either side.  The chain's reach: 8 DE
+# directions x (15 taps + the 9 rows of the two density blurs at the outermost tap) = 192 rows; the tone filters
+# are per pixel.  A multiple of 16 (a band must be a valid accumulator height).
+BAND_HALO = 224
+
+
+def band_plan(ah, world, halo=BAND_HALO):
+    """
+    Row bands of an accumulator of ``ah`` rows for ``world`` ranks: ``(rows_per, [(r0, r1)] per rank)`` with
+    every r0 / r1 a multiple of 16 and equal ``rows_per`` (what reduce-scatter needs; the last bands may be
+    short or empty), or None when bands make no sense (one rank, or a band shorter than its halo).
+    """
+    if world < 2:
+        return None
+    rows_per = 16 * -(-ah // (16 * world))
+    if rows_per < halo:
+        return None
+    return rows_per, [(min(r * rows_per, ah), min((r + 1) * rows_per, ah)) for r in range(world)]
+
+
+def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO):
+    """
+    ``acc2d``: this rank's accumulator as a (ah, row_floats) tensor.  Sums it over the ranks by bands and
+    returns ``(band, top)``: the summed rows ``[r0 - top, r1 + bottom)`` of this rank's band with its
+    halos (``top`` / ``bottom`` = halo, or 0 at the image's own edges), as a new tensor.
+    Collective: every rank calls it.  RCCL: one reduce-scatter + two neighbour exchanges; gloo (CPU
+    tests) has no reduce-scatter: all-reduce, then the same slicing.
+    """
+    rows_per, bands = plan
+    ah, rowf = acc2d.shape
+    r0, r1 = bands[rank]
+    if dist.get_backend() == 'nccl':
+        padded = acc2d
+        if rows_per * world != ah:                       # reduce-scatter wants equal chunks
+            padded = torch.zeros((rows_per * world, rowf), dtype=acc2d.dtype, device=acc2d.device)
+            padded[:ah] = acc2d
+        core = torch.empty((rows_per, rowf), dtype=acc2d.dtype, device=acc2d.device)
+        dist.reduce_scatter_tensor(core, padded, op=dist.ReduceOp.SUM)
+        core = core[:r1 - r0]
+        # halos: the neighbours' outermost summed rows (bands are at least `halo` rows tall, except
+        # possibly the last non-empty one, which then sends what it has)
+        up, down = rank - 1, rank + 1
+        top = torch.empty((halo if r0 > 0 else 0, rowf), dtype=acc2d.dtype, device=acc2d.device)
+        nbot = min(halo, max(ah - r1, 0))
+        bot = torch.empty((nbot, rowf), dtype=acc2d.dtype, device=acc2d.device)
+        ops = []
+        if r1 > r0:
+            if r0 > 0:
+                ops.append(dist.P2POp(dist.isend, core[:halo].contiguous(), up))
+                ops.append(dist.P2POp(dist.irecv, top, up))
+            if nbot > 0:
+                ops.append(dist.P2POp(dist.isend, core[-halo:].contiguous(), down))
+                ops.append(dist.P2POp(dist.irecv, bot, down))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return torch.cat([top, core, bot]), top.shape[0]
+    dist.all_reduce(acc2d, op=dist.ReduceOp.SUM)
+    top = halo if r0 > 0 else 0
+    return acc2d[r0 - top:min(r1 + halo, ah)].clone(), top
+
+
+def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
+    """
+    Run the profile's filter chain and the output conversion on ``band`` — summed accumulator rows, (rows,
+    astride * 4) floats, rows a multiple of 16 — as an image of its own in ``mgr``'s context.  The filters'
+    host-derived scalars are those of the FULL frame (``dim``: the spatial deviation scales with the width, the
+    log scale with the frame's area).  Returns the band's finished 8-bit pixels as a device tensor of
+    (rows - 24, w, 4): row j is accumulator row j + 12 of the band, as in a whole frame.  ``convert=False``
+    stops after the filters (tests: the float result is in the context's front buffer) and returns (None, bdim).
+    """
+    from . import _lib
+    from .render import Dimensions
+    rows = int(band.shape[0])
+    assert rows % 16 == 0 and rows >= 32 and band.shape[1] == dim.astride * 4
+    bdim = Dimensions(dim.w, rows - 2 * mgr.fb.gutter, dim.aw, rows, dim.astride)
+    assert mgr.fb.calc_dim(bdim.w, bdim.h) == bdim
+    _lib.check(_lib.load().fl_ctx_sync(mgr.fb.ctx))                 # whatever still uses the buffers
+    front = accumulator_tensor(mgr.fb, device, dim)
+    front[:band.numel()].copy_(band.reshape(-1))
+    torch.cuda.synchronize(device)
+    for filt in rdr.filts:
+        params = getattr(gprof.filters, filt.name)
+        filt._run(mgr.fb, bdim, filt.scalars(gprof, params, dim, tc))
+    if not convert:
+        return None, bdim
+    out = torch.empty((bdim.h, bdim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=front.device)
+    rdr.out.convert(mgr.fb, gprof, bdim)
+    rdr.out.copy(mgr.fb, bdim, dev_out=out.data_ptr(), host=False)
+    return out, bdim
+
+
+def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=True):
     """
     RenderManager.queue_frame for ONE frame split by samples over all ranks.  Every rank must
     call it (it contains the collective) with a RenderManager built with
@@ -285,6 +382,30 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True):
     _lib.check(lib.fl_iterate(fb.ctx, g, dim.w, dim.h, float(nsamps), mgr.fuse,
                               mgr.resolve_accum_mode(dim), C.byref(run)))
     mgr.last_nsamples = run.value
+    plan = band_plan(dim.ah, world) if (bands and rdr.out.dtype in ('u1', 'u2') and len(rdr.out.shape(dim)) == 3) else None
+    if world > 1 and plan is not None:
+        # row bands: reduce-scatter + halo exchange, filter and convert the band, all-gather the 8-bit rows
+        acc = accumulator_tensor(fb, device, dim).view(dim.ah, dim.astride * 4)      # waits for the iterate + flush kernels
+        band, top = exchange_bands(acc, plan, rank, world)
+        rows_per, ranges = plan
+        r0, r1 = ranges[rank]
+        g = fb.gutter
+        mine = torch.zeros((rows_per, dim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=acc.device)
+        if r1 > r0:
+            out, bdim = filter_band(mgr, rdr, gprof, dim, band, tc, device)
+            # image rows of this band: accumulator rows [r0, r1) less the frame's own gutter rows
+            y0, y1 = max(r0 - g, 0), min(r1 - g, dim.h)
+            if y1 > y0:
+                j0 = y0 + g - (r0 - top) - g                 # band output row of image row y0
+                _lib.check(lib.fl_ctx_sync(fb.ctx))
+                mine[y0 + g - r0:y1 + g - r0] = out[j0:j0 + (y1 - y0)]
+        allb = torch.empty((world * rows_per, dim.w, 4), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(allb, mine) if dist.get_backend() == 'nccl' else dist.all_gather(list(allb.view(world, rows_per, dim.w, 4).unbind(0)), mine)
+        frame = allb[g:g + dim.h]
+        h_out = fb.host_buffer(rdr.out.shape(dim), rdr.out.dtype)
+        h_out[...] = frame.cpu().numpy().view(h_out.dtype)
+        _lib.check(lib.fl_ctx_sync(fb.ctx))
+        return DurationEvent(fb, fid.value), h_out
     if world > 1:
         acc = accumulator_tensor(fb, device, dim)      # waits for the iterate + flush kernels
         sum_accumulators(acc)

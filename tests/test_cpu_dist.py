@@ -320,3 +320,49 @@ def test_bench_gpus_2_starts_two_ranks():
     # a launcher that started the wrong number of ranks is an error, not a silent one-GPU run
     p, lines = _bench(['--gpus', '2', '--dry-run'], env={'WORLD_SIZE': '1', 'RANK': '0'})
     assert p.returncode != 0 and not lines
+
+
+BAND_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from cuburn_amd import distributed as D
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
+                            rank=int(os.environ['RANK']), world_size=2)
+    rank, world = dist.get_rank(), 2
+    for ah in (1104, 480, 2192):
+        accs = [np.random.RandomState(100 * ah + r).rand(ah, 12).astype(np.float32) for r in range(world)]
+        total = accs[0] + accs[1]
+        plan = D.band_plan(ah, world)
+        assert plan is not None
+        rows_per, ranges = plan
+        assert rows_per %% 16 == 0 and ranges[0][0] == 0 and ranges[-1][1] == ah
+        band, top = D.exchange_bands(torch.from_numpy(accs[rank].copy()), plan, rank, world)
+        r0, r1 = ranges[rank]
+        assert top == (D.BAND_HALO if r0 > 0 else 0)
+        want = total[r0 - top:min(r1 + D.BAND_HALO, ah)]
+        assert band.shape == want.shape and band.shape[0] %% 16 == 0, (band.shape, want.shape)
+        assert np.array_equal(band.numpy(), want)
+    assert D.band_plan(400, 2) is None and D.band_plan(1104, 1) is None          # bands shorter than the halo; one rank
+    if rank == 0:
+        print('BANDS_OK')
+    dist.barrier()
+    dist.destroy_process_group()
+''') % REPO
+
+
+def test_row_band_exchange_world2(tmp_path):
+    """Sample-sharded frames are summed by row bands: every rank ends up with the sum of its own rows plus 224
+    halo rows from its neighbours (reduce-scatter + neighbour exchange on RCCL; the gloo stand-in all-reduces
+    and slices — same rows, same values)."""
+    script = tmp_path / 'worker.py'
+    script.write_text(BAND_WORKER)
+    port = str(29700 + os.getpid() % 200)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'BANDS_OK' in outs[0]

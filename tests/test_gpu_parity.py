@@ -1016,6 +1016,55 @@ def test_sample_sharded_frame_two_virtual_ranks(built):
         m.fb.free()
 
 
+@pytest.mark.parametrize('world', [2, 4])
+def test_band_filtering_matches_whole_frame(built, world):
+    """Sample-sharded frames filter by row bands (distributed.py): a band of summed accumulator rows plus 224 halo
+    rows on either side is filtered as an image of its own, with the FULL frame's scalars.  On one GPU: cut the
+    accumulator of a 1080p frame into the bands `world` ranks would own, filter each band, stitch the bands' own rows
+    together, and compare with the chain run on the whole frame.  The filters are local and the halo exceeds the
+    chain's reach (8 x 24 rows), so the interior is the same computation; tiles that touch a band's artificial edge
+    take the nested form of the density blurs where the whole frame takes the regrouped 19-tap form (de.hip): 1e-7
+    relative in the blurred density, far below the bar."""
+    import torch
+    from cuburn_amd import distributed as D
+    gnm, prof = configs.cfg2()
+    prof = dict(prof, spp=2 ** 26 / (1920.0 * 1080.0))
+    gprof = profile.wrap(prof, gnm)
+    m = render.RenderManager(device=0, host_seed=9)
+    rdr = render.Renderer(gnm, gprof)
+    lib = _lib.load()
+    tc = 0.5
+    dim = m.fb.set_dim(gprof.width, gprof.height)
+    ts, td = frame_times(gprof, tc)
+    fid = C.c_uint32()
+    _lib.check(lib.fl_frame_begin(m.fb.ctx, C.byref(fid)))
+    m._copy(rdr, gnm)
+    g = rdr._handle(m.fb)
+    _lib.check(lib.fl_interp(m.fb.ctx, g, dim.w, dim.h, ts, td))
+    run = C.c_uint64()
+    _lib.check(lib.fl_iterate(m.fb.ctx, g, dim.w, dim.h, float(2 ** 26), m.fuse, m.resolve_accum_mode(dim), C.byref(run)))
+    acc = m.fb.read('front', (dim.ah, dim.astride * 4), np.float32)
+    for filt in rdr.filts:
+        filt.apply(m.fb, gprof, getattr(gprof.filters, filt.name), dim, tc)
+    whole = m.fb.read('front', (dim.ah, dim.astride * 4), np.float32)
+    assert whole.max() > 0.5
+
+    plan = D.band_plan(dim.ah, world)
+    assert plan is not None and all(r0 % 16 == 0 and r1 % 16 == 0 for r0, r1 in plan[1])
+    assert plan[1][0][0] == 0 and plan[1][-1][1] == dim.ah and all(a[1] == b[0] for a, b in zip(plan[1], plan[1][1:]))
+    stitched = np.zeros_like(whole)
+    for r0, r1 in plan[1]:
+        top = D.BAND_HALO if r0 > 0 else 0
+        band = torch.from_numpy(acc[r0 - top:min(r1 + D.BAND_HALO, dim.ah)].copy()).cuda()
+        _, bdim = D.filter_band(m, rdr, gprof, dim, band, tc, 0, convert=False)
+        res = m.fb.read('front', (bdim.ah, dim.astride * 4), np.float32)
+        stitched[r0:r1] = res[top:top + (r1 - r0)]
+    err = np.abs(stitched - whole)
+    assert err.max() < 2e-5 and err.mean() < 1e-7, (err.max(), err.mean())
+    assert D.band_plan(dim.ah, 8) is None and D.band_plan(4352, 8)[0] == 544      # 1080p bands of 8 ranks are shorter than their halo; 8K: 544 rows
+    m.fb.free()
+
+
 def test_flam3_xml_to_frame(mgr, tmp_path):
     """Front end to pixels: flam3 XML -> node -> looping animation (genome.store) -> queue_frame."""
     import json
