@@ -83,6 +83,9 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 #ifndef DE_TH_
 #define DE_TH_ 32
 #endif
+#ifndef DE_TWE_
+#define DE_TWE_ DE_TW_ /* directions 4 and 6 (two pixels per row: even shear, consecutive rows per wave) */
+#endif
 #ifndef DE_TWH_
 #define DE_TWH_ 8      /* directions 1..3 (integer steps, no column halo): 32 x 8, 256 threads */
 #endif
@@ -128,7 +131,7 @@ __host__ __device__ constexpr DeReach de_reach(int P, bool blur)
 template <int P> struct DeGeo {
     static constexpr int K = de_k(P);
     // output tile
-    static constexpr int TW = P == 0 ? DE_TW0_ : (de_hoisted(P) ? DE_TWH_ : DE_TW_);
+    static constexpr int TW = P == 0 ? DE_TW0_ : (de_hoisted(P) ? DE_TWH_ : (P == 4 || P == 6) ? DE_TWE_ : DE_TW_);
     static constexpr int TH = P == 0 ? DE_TH0_ : (de_hoisted(P) ? DE_THH_ : DE_TH_);
     static constexpr int NT = TW * TH;                  // threads of a workgroup = output pixels of a tile
     static_assert(NT % 64 == 0 && NT <= 1024 && (P == 0 ? TW % 64 == 0 : 64 % TW == 0 && TH % (128 / TW) == 0), "whole waves, rows of equal parity per wave");
@@ -571,9 +574,14 @@ taps:
     const int wv = tid >> 6, lane = tid & 63;
     int ou, ov;
     if (P == 0) { constexpr int WPR = G::TW / 64; ou = wv / WPR; ov = (wv % WPR) * 64 + lane; }
-    else {
+    else if (G::K & 1) {
         constexpr int RPW = 64 / G::TW;                                   // rows per wave (equal parity)
         ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW); ov = lane % G::TW;
+    } else {
+        // even K: no parity to respect, so a wave takes CONSECUTIVE rows — with 8-pixel rows (128 bytes) two rows two
+        // apart start on the same LDS bank, and the 16 lanes a ds_read_b128 serves together span two rows
+        // (SQ_LDS_BANK_CONFLICT was 40 % of the LDS cycles of direction 1 with the equal-parity mapping)
+        ou = wv * (64 / G::TW) + lane / G::TW; ov = lane % G::TW;
     }
     const int ci = (ou + G::HA) * G::COLS + ov + G::HV;
     const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
