@@ -562,7 +562,7 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, int 
     if (*nbins > FL_MAX_BINS_WIDE) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 8191 tiles of 256x64)", __FILE__, __LINE__);
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
-    size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt, dw = (size_t)*nbins * *nbatch_total;
+    size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt * FL_REC_BYTES / 4 + 8, dw = (size_t)*nbins * *nbatch_total;      // records of FL_REC_BYTES bytes (+ slack for the last record's 4-byte load)
     if (lw > L(c).log_words[buf]) {
         HIPCHK(hipStreamSynchronize(L(c).stream)); HIPCHK(hipStreamSynchronize(L(c).aux));
         hipFree(L(c).d_log[buf]); L(c).d_log[buf] = nullptr; L(c).log_words[buf] = 0;

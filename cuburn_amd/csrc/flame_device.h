@@ -90,6 +90,9 @@ __device__ __forceinline__ uint32_t trunca(float f) {
 #define FL_TILE_H (1u << FL_TILE_H_LOG2)
 #define FL_TILE_CELLS (FL_TILE_W * FL_TILE_H)
 #define FL_REC_BITS (15u + FL_TILE_H_LOG2)   /* ly + lx 7 + ci 8 */
+#ifndef FL_REC_BYTES
+#define FL_REC_BYTES 4    /* bytes of a sample-log record in HBM: 4, or 3 (packed: 21 / 22 payload bits) */
+#endif
 #define FL_MAX_BINS 2047u                      /* 128x64 tiles: tile number shares the 32-bit staged record */
 #define FL_TILE_W_WIDE_LOG2 8u                 /* 256x64 tiles for larger images (tile number staged separately) */
 #define FL_MAX_BINS_WIDE 8191u

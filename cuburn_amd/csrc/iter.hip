@@ -495,9 +495,24 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;
-                uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
                 const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+#if FL_REC_BYTES == 3
+                // records are 21 / 22 bits (row | column | palette column): four of them leave as three words —
+                // the log is what the accumulate streams, and it is bound by those bytes
+                {
+                    struct __attribute__((packed, aligned(4))) W3 { uint32_t a, b, c; };
+                    W3 *dst = reinterpret_cast<W3 *>(reinterpret_cast<unsigned char *>(bin_log) + (size_t)batch_id * bg.rounds * NT * 3u);
+                    for (uint32_t i = tid; i * 4 < nvalid; i += NT) {
+                        const uint4 r = src[i];
+                        W3 o;
+                        o.a = r.x | (r.y << 24); o.b = (r.y >> 8) | (r.z << 16); o.c = (r.z >> 16) | (r.w << 8);
+                        dst[i] = o;
+                    }
+                }
+#else
+                uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
+#endif
                 for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
                 ++batch_in_slot;
                 __syncthreads();

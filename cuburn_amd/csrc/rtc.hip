@@ -126,6 +126,7 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #ifdef FL_CNT_SETS_BIG
                           "-DFL_CNT_SETS_BIG=" FL_STR(FL_CNT_SETS_BIG),
 #endif
+                          "-DFL_REC_BYTES=" FL_STR(FL_REC_BYTES),
                           "-fno-slp-vectorize",
     };
     const hiprtcResult rc = a.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
