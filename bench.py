@@ -402,7 +402,7 @@ def main():
                          'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file else None,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
-                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'VALU / SALU issue (not bandwidth)',
+                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'vector / scalar issue and the per-round barrier (65 % of the wall-clock VALU peak; not bandwidth)',
                                     'measured_bytes_per_launch': iter_bytes,
                                     'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
                                     'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
@@ -413,7 +413,7 @@ def main():
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
                           'traffic': de_traffic,
-                          'bound': 'VALU issue (SQ counters in profiles/): 512 B/px is the algorithmic byte count of the reference pass structure'},
+                          'bound': 'workgroup phase latency x vector ALU (DESIGN 4.3: 55-65 % of the wall-clock VALU peak, 15 % of HBM): 512 B/px is the algorithmic byte count of the reference pass structure'},
             'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),
                                     'filters': round(acc['filter_ms'] / ksteps, 4), 'note': 'un-overlapped (single stream lane)'},
         }
