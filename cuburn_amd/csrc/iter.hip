@@ -37,6 +37,9 @@
 #ifndef FL_CNT_SETS
 #define FL_CNT_SETS 3          /* sets of tile counters per 4-wave workgroup (LDS: an array of tiles + 1 words each) */
 #endif
+#ifndef FL_ITER_ROT3
+#define FL_ITER_ROT3 1
+#endif
 #ifndef FL_CNT_SETS_BIG
 #define FL_CNT_SETS_BIG 2      /* the same for 8- and 16-wave workgroups (many tiles: scanning more sets costs more than it saves) */
 #endif
@@ -292,7 +295,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
     // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
     uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
-    auto advance = [&]() __attribute__((always_inline)) {
+    auto advance = [&](const uint32_t dst) __attribute__((always_inline)) {
         if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
 
         const int k_cur = k_next;
@@ -314,8 +317,6 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
-            const uint32_t dst = rot0;
-            rot0 = rot1; rot1 = rot2; rot2 = dst;           // the three-phase destination cycle
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
@@ -333,15 +334,38 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 #endif
     // (a kernel with many heavy xforms keeps ONE copy of the walk: there the fuse rounds run through the
     // plotting loop with the plot skipped — a second copy of twelve inlined xforms cost cfg5 7 %)
-    if (SPLIT_FUSE) for (uint32_t rd = 0; rd < nfuse; ++rd) advance();
+    // The swap destination cycles through three values (phase = round % 3).  Rotating three registers costs three
+    // v_mov per round; small kernels instead carry THREE copies of the round, one per destination, entered at the
+    // current phase (ROT3; kernels of many heavy xforms keep one copy and rotate).
+    constexpr bool ROT3 = SPLIT_FUSE && FL_ITER_ROT3;
+    uint32_t ph = 0;                                    // which of rot0 / rot1 / rot2 the next round uses (ROT3)
+    auto next_dst = [&]() __attribute__((always_inline)) -> uint32_t {      // one copy: rotate
+        const uint32_t dst = rot0;
+        rot0 = rot1; rot1 = rot2; rot2 = dst;
+        return dst;
+    };
+    // run `body(dst, i)` for i = from .. to - 1 with the destinations in cycle
+    auto rounds = [&](uint32_t from, uint32_t to, auto body) __attribute__((always_inline)) {
+        if constexpr (ROT3) {
+            uint32_t i = from;
+            while (i < to) {
+                if (ph == 0u) { body(rot0, i); ph = 1u; if (++i == to) break; }
+                if (ph == 1u) { body(rot1, i); ph = 2u; if (++i == to) break; }
+                body(rot2, i); ph = 0u; ++i;
+            }
+        } else {
+            for (uint32_t i = from; i < to; ++i) body(next_dst(), i);
+        }
+    };
+    if (SPLIT_FUSE) rounds(0u, nfuse, [&](uint32_t dst, uint32_t) __attribute__((always_inline)) { advance(dst); });
     uint32_t fuse_left = SPLIT_FUSE ? 0u : nfuse;
     for (uint32_t rd = SPLIT_FUSE ? nfuse : 0u; rd < nrounds;) {
     const uint32_t blen = fuse_left ? fuse_left : BINNED ? min(bg.rounds, nrounds - rd) : nrounds - rd;
     const bool plotting = fuse_left == 0u;
     fuse_left = 0u;
-    for (uint32_t staged = 0; staged < blen; ++staged) {
-        advance();
-        if (!SPLIT_FUSE && !plotting) continue;
+    rounds(0u, blen, [&](const uint32_t dst, const uint32_t staged) __attribute__((always_inline)) {
+        advance(dst);
+        if (!SPLIT_FUSE && !plotting) return;
 
         float fx = x, fy = y, fc = color;
 #ifdef FL_RTC
@@ -400,7 +424,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             pend_old += ok ? val + gi : 0ull;
         }
         if (COUNT) n_acc += ok;
-    }
+    });
     rd += blen;
     if (BINNED && plotting) {
             {
