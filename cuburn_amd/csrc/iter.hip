@@ -283,9 +283,11 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     // Wave-coherent xform choice: lane 0's draw (iter.py:260-272 uses a shared cosel[]).  The
     // selector of round r+1 is drawn at the top of round r, so the record it picks can be
     // fetched a whole round before it is needed.
+    const unsigned long long valid_lanes = __ballot(thr_valid);            // scalar, once per launch
     auto choose = [&](uint32_t sel) -> int {
-        // smallest i with sel <= T_i; nxf - 1 if there is none
-        const unsigned long long le = __ballot(thr_valid && sel <= thr) | (1ull << 63);
+        // smallest i with sel <= T_i; nxf - 1 if there is none.  (The valid lanes are ANDed in on the scalar side:
+        // `__ballot(thr_valid && ...)` made the compiler rebuild the predicate in a VGPR: 3 vector instructions, now 1.)
+        const unsigned long long le = (__ballot(sel <= thr) & valid_lanes) | (1ull << 63);
         return min((int)__builtin_ctzll(le), nxf - 1);
     };
     uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
@@ -398,7 +400,8 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             }
         }
         const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
-        const int ci = (int)__builtin_rintf(fminf(fmaxf(cf, 0.0f), 255.0f));
+        // rint of a value in [0, 255] = the low mantissa bits of (value + 2^23): the float adder rounds to nearest even
+        const int ci = (int)((__float_as_uint(fminf(fmaxf(cf, 0.0f), 255.0f) + 8388608.0f) - 0x4b000000u) & 0xffu);
         const u64 val = BINNED ? 0ull : palrow[ci];                         // iter.py:351
 
         // Every add returns the previous cell value, but the value is only looked at one
