@@ -27,11 +27,11 @@
 //     1.21 ns per SIMD); a kernel then pays ~8-10 us of ramp-up and tail on top (every workgroup stages at the start,
 //     few are left at the end).  The tap arithmetic is arranged for the fewest instructions.  The colour
 //     distance |n_q - c|^2 is expanded: cs*|n_q|^2 is a per-pixel plane S, -2*cs*c a per-centre
-//     vector C', and cs*|c|^2 — common to every tap of a centre — is factored out of the loop
-//     altogether (all five sums scale by 2^(cs*|c|^2), which is undone once at the end):
-//         e = S_q + n_q . C'   (3 fma; "dead" tap or centre: a select to cs/2 - cs*|c|^2)
+//     vector C', and cs*|c|^2 a per-centre scalar added to S (NOT factored out of the loop: for narrow
+//     colour kernels the partial exponent overflows, see de_tap_loop):
+//         e = S_q + cs*|c|^2 + n_q . C'   (1 add + 3 fma; "dead" tap or centre: a select to cs/2)
 //           - | |ds|*pw_c - |ds|*pw_q |  - H(q)          (|ds|*w^dpow is a per-pixel plane too)
-//     12 -> 8 instructions in front of the exponential.
+//     17 vector instructions per tap, one of them the exponential.
 //   * Image edges.  The reference clamps every texture fetch (cuburn/code/filters.py:22-35), which
 //     makes the blurred density at a tap outside the image the blur AT the clamped position, not
 //     the blur of the clamped image.  Staged positions outside the image (they exist only in
