@@ -74,7 +74,7 @@ __device__ __forceinline__ void apply_xf(const XfHead &h, const float *__restric
     const int nvar = word14 & 0xff;
     float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, h.f[2]));
     float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, h.f[5]));
-    float ox = 0.0f, oy = 0.0f;
+    float ox = -0.0f, oy = -0.0f;          // -0 + v = v for every v (IEEE): the first variation's add folds away (the CPU model of the tests starts at -0 as well)
     if (nvar > 0) apply_variation(h.vid0, h.w0, xf + FL_XF_HDR + 2, xf, tx, ty, ox, oy, r);
     for (int j = 1; j < nvar; ++j) {
         const float *__restrict__ v = xf + FL_XF_HDR + j * var_stride;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void spec_apply_xf(const XfHead &h, const float *__re
 {
     float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, h.f[2]));
     float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, h.f[5]));
-    float ox = 0.0f, oy = 0.0f;
+    float ox = -0.0f, oy = -0.0f;          // -0 + v = v for every v (IEEE): the first variation's add folds away (the CPU model of the tests starts at -0 as well)
     spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
     if constexpr (kSpecPost[I] != 0) {
         const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, h.f[8]));

@@ -614,7 +614,7 @@ int ref_apply_xf(const int32_t *prog, const float *P, int xfi, float *px, float 
     float x = *px, y = *py;
     float tx = fmaf(xf[0], x, fmaf(xf[1], y, xf[2]));
     float ty = fmaf(xf[3], x, fmaf(xf[4], y, xf[5]));
-    float ox = 0.0f, oy = 0.0f;
+    float ox = -0.0f, oy = -0.0f;        /* as the device: -0 + v = v exactly, so the sum is the variations' own (a sum of +0 terms only differs in the sign of zero) */
     for (int j = 0; j < nvar; ++j) {
         const float *v = xf + 16 + j * vstride;
         int32_t vid;
