@@ -169,7 +169,7 @@ def _blocks16(a, dim):
 # linear, block L1 0.11 at fuse 64, 0.010 at 256).  Everything here runs at RenderManager's DEFAULTS,
 # through queue_frame: no explicit fuse, production slots.  The CPU sample uses 64 trajectories (eight
 # trajectories of a map that does not mix are not a distribution).
-@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102])
+@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102, 110, 176])
 def test_single_xform_genome_default_schedule(seed):
     gnm, prof = random_genome(seed)
     assert len(gnm['xforms']) == 1
