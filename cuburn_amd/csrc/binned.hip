@@ -72,14 +72,35 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifndef ACC_ILP
 #define ACC_ILP 4
 #endif
+#ifndef ACC_ADD_ILP
+#define ACC_ADD_ILP 8          /* returning global atomics in flight per thread when the tile is added to the accumulator */
+#endif
+#ifndef ACC_ROWS_MAX
+#define ACC_ROWS_MAX 5         /* palette rows staged per narrow workgroup (2 KB each) */
+#endif
 #ifndef ACC_THREADS
 #define ACC_THREADS 1024        /* threads per accumulate workgroup (narrow tiles) */
 #endif
 
+// -DACC_X_TIMES: every workgroup stores its start and end (100 MHz ticks) in acc_wg_times[blockIdx.x]; fl_debug_acc_times
+// copies them out (tools/acc_times.py: which tiles' workgroups run longest, and when)
+#ifdef ACC_X_TIMES
+#define ACC_X_MAXWG 65536
+__device__ unsigned long long acc_wg_times[ACC_X_MAXWG][4];      // start, tile zeroed + first palette rows staged, records done, tile added
+extern "C" __attribute__((visibility("default"))) int fl_debug_acc_times(unsigned long long *out, unsigned n)
+{
+    if (n > ACC_X_MAXWG) n = ACC_X_MAXWG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(acc_wg_times), sizeof(unsigned long long) * 4 * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // TWL: log2 of the tile width (7: 128x64 tiles = 64 KB of LDS cells, two workgroups per CU;
 // 8: 256x64 tiles = 128 KB, for images with more than 2047 narrow tiles)
+// 80 SGPRs including VCC etc.: two 16-wave workgroups per CU need 8 waves per SIMD, and a CU of this GPU holds
+// 8 waves per SIMD only up to 80 SGPRs per wave (measured: tools/occupancy_probe.hip,
+// profiles/r03_occupancy_probe.txt; the compiler's table and the occupancy API say 96)
 template <uint32_t TWL>
-__global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024)
+__global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024) __attribute__((amdgpu_num_sgpr(80)))
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
@@ -88,12 +109,17 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
     constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;
-    u64 *tile = reinterpret_cast<u64 *>(smem);                     // [CELLS]
-    uint32_t *mk = reinterpret_cast<uint32_t *>(smem + CELLS * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
-    u64 *pal = reinterpret_cast<u64 *>(smem + CELLS * 8 + blockDim.x * 4);                     // [rows_cap][256] palette rows in use
+    static_assert(FL_PAL_W == 256, "the palette column is the record's low byte, the row the mark's");
+    // LDS: palette rows first (their gather then needs no base added), the waves' marks, the tile
+    u64 *pal = reinterpret_cast<u64 *>(smem);                                                   // [rows_cap][256] palette rows in use
+    uint32_t *mk = reinterpret_cast<uint32_t *>(smem + rows_cap * FL_PAL_W * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
+    u64 *tile = reinterpret_cast<u64 *>(smem + rows_cap * FL_PAL_W * 8 + blockDim.x * 4);       // [CELLS]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
     const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
+#ifdef ACC_X_TIMES
+    if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
 
     // This workgroup's contiguous range of batches.  Batch id = slot * per_slot + batch_in_slot
@@ -134,6 +160,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         if (i < nrows * FL_PAL_W) pal[i] = stagev[q];
     }
     __syncthreads();
+#ifdef ACC_X_TIMES
+    if (tid == 0 && blockIdx.x < ACC_X_MAXWG && cb == b_lo) acc_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t g0v = cb + wv * 64; g0v < ce; g0v += nwaves * 64) {
         const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0v);      // wave-uniform
         // slot of the group's first batch and the remainder, once per group (scalar); run r < 64 of
@@ -146,19 +175,29 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
         const uint32_t total = __shfl(incl, 63);
-        // Which run does record v of the virtual array belong to?  Every non-empty run drops a
-        // mark (run number | source offset - v) at its first position; a max-scan over the
-        // positions (DPP, pure VALU) then carries the latest mark to every position.  This
-        // replaces a 6-step shuffle binary search + two more shuffles per record (8 trips through
-        // the LDS pipe) by one predicated LDS write, one read and one clear per 64 records.
+        // Which run does record v of the virtual array belong to?  Every non-empty run drops a mark at its first
+        // position; a max-scan over the positions (DPP, pure VALU) then carries the latest mark to every position.
+        // This replaces a 6-step shuffle binary search + two more shuffles per record (8 trips through the LDS pipe)
+        // by one predicated LDS write, one read and one clear per 64 records.  The mark holds everything a record
+        // needs from its run, computed ONCE per run by the run's directory lane:
+        //   bits 8..: 1 + (lane * batch_records + first - excl) = 1 + (the record's index in the log, counted from
+        //             the group's first batch) - (its position v in the virtual array)
+        //   bits 0-7: the run's palette row among the staged rows (a whole byte: v_perm joins it with the record's colour byte)
+        // The upper field never decreases from one run to the next (first' + batch_records >= first + c: a run ends
+        // inside its batch) and is the same only where the record index is the same anyway; the row never decreases
+        // either, so the LARGEST mark at or before a position is the mark of the run the position belongs to.
+        const uint32_t rslot_l = s0 + (uint32_t)(((float)(rem0 + lane) + 0.5f) * inv_ps);          // exact: small integers
+        const uint32_t row_l = (uint32_t)(((float)rslot_l + 0.5f) * inv_spr) - row_lo;              // row within the staged rows
+        const uint32_t mark_l = ((lane * batch_records + first - excl + 1u) << 8) | (row_l & 255u);
+        const unsigned char *gbase = reinterpret_cast<const unsigned char *>(log + (size_t)g0 * batch_records) - 4;   // (the marks' "1 +")
         uint32_t carry = 0;
         for (uint32_t v0 = 0; v0 < total; v0 += 64 * ILP) {
-            uint32_t rec[ILP], row[ILP];
+            uint32_t rec[ILP], poff[ILP];                           // poff: the mark (its low byte is the palette row)
             bool live[ILP];
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
                 const uint32_t lo = v0 + k * 64, v = lo + lane;
-                if (c != 0u && excl - lo < 64u) mk[excl - lo] = (lane << 24) | ((first - excl) & 0xffffffu);
+                if (c != 0u && excl - lo < 64u) mk[excl - lo] = mark_l;
                 wave_sync();                 // lanes exchange data through LDS: without it the compiler
                 uint32_t m = mk[lane];       // forwards this lane's own earlier "= 0" into the load
                 wave_sync();
@@ -166,35 +205,31 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 m = wave_incl_maxscan(m);
                 m = max(m, carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
-                const uint32_t r = m >> 24;
-                const int delta = (int)(m << 8) >> 8;                         // first[r] - excl[r], sign-extended
                 live[k] = v < total;
-                const uint32_t rbatch = g0 + r;
-#ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
-                rec[k] = live[k] ? ((rbatch * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u)) + (delta & 0) : 0u;
-#else
-#if FL_REC_BYTES == 3
-                // 3-byte records: the two aligned words around the record's byte address in ONE 8-byte load (needs 4-byte
-                // alignment only), the record cut out with v_alignbyte — an unaligned 4-byte load measured +31 %
+                rec[k] = 0u; poff[k] = 0u;
                 if (live[k]) {
-                    const size_t ba = ((size_t)rbatch * batch_records + (uint32_t)((int)v + delta)) * 3u;
+#ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
+                    rec[k] = ((m * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u));
+#elif FL_REC_BYTES == 3
+                    // 3-byte records: the two aligned words around the record's byte address in ONE 8-byte load (needs 4-byte
+                    // alignment only), the record cut out with v_alignbyte — an unaligned 4-byte load measured +31 %
+                    const size_t ba = ((size_t)g0 * batch_records + (v + (m >> 8) - 1u)) * 3u;
                     struct __attribute__((packed, aligned(4))) W2 { uint32_t lo, hi; };
                     const W2 w = *reinterpret_cast<const W2 *>(reinterpret_cast<const unsigned char *>(log) + (ba & ~(size_t)3));
                     rec[k] = __builtin_amdgcn_alignbyte(w.hi, w.lo, (uint32_t)ba & 3u) & 0xffffffu;
-                } else rec[k] = 0u;
 #else
-                rec[k] = live[k] ? log[(size_t)rbatch * batch_records + (uint32_t)((int)v + delta)] : 0u;
+                    // scalar base + 32-bit byte offset (at most 4 * 65 * batch_records)
+                    rec[k] = *reinterpret_cast<const uint32_t *>(gbase + (size_t)(uint32_t)(((m >> 8) + v) << 2));
 #endif
-#endif
-                const uint32_t rslot = s0 + (uint32_t)(((float)(rem0 + r) + 0.5f) * inv_ps);     // exact: small integers
-                row[k] = live[k] ? (uint32_t)(((float)rslot + 0.5f) * inv_spr) - row_lo : 0u;     // row within the staged rows
+                    poff[k] = m;
+                }
             }
             u64 val[ILP];
 #pragma unroll
 #ifdef ACC_X_NOPAL
-            for (int k = 0; k < ILP; ++k) val[k] = (1ull << 54) | row[k] | (rec[k] & 0xffu);
+            for (int k = 0; k < ILP; ++k) val[k] = (1ull << 54) | (poff[k] & 0xffu) | (rec[k] & 0xffu);
 #else
-            for (int k = 0; k < ILP; ++k) val[k] = pal[row[k] * FL_PAL_W + (rec[k] & 0xffu)];
+            for (int k = 0; k < ILP; ++k) val[k] = pal[__builtin_amdgcn_perm(poff[k], rec[k], 0x0c0c0400u)];      // (row << 8) | colour byte: FL_PAL_W == 256
 #endif
             // A cell that takes most of the samples (a point attractor takes all of them) would receive
             // thousands of adds between the moment its count passes the drain threshold and the moment
@@ -244,23 +279,56 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 
     // add the tile to the global packed accumulator: one row segment of 64 cells per wave
     // instruction (coalesced atomics), draining cells that reach 512 hits
+#ifdef ACC_X_TIMES
+    __syncthreads();
+    if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef ACC_NO_DRAIN     /* timing experiment only: tools/exp_drain.sh */
-    for (uint32_t i = tid; i < CELLS; i += blockDim.x) {
-        const u64 v = tile[i];
-        const uint32_t px = tx * TW + (i & (TW - 1u)), py = ty * FL_TILE_H + (i >> TWL);
-        if (v != 0ull && px < astride && py < aheight) {
-            const uint32_t gi = py * astride + px;
-            // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
-            // most `nparts` adds per launch (one per workgroup of its tile) onto a flushed cell,
-            // so chunks below 1024/nparts hits are safe; larger ones go straight to the floats.
-            if ((uint32_t)(v >> 54) >= 1024u / nparts) { spill_cell(v, gi, out4); continue; }
-            const u64 old = __hip_atomic_fetch_add(atom + gi, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(old >> 32) >= (256u << 23)) {
-                const u64 cur = __hip_atomic_exchange(atom + gi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(cur >> 32) != 0u) spill_cell(cur, gi, out4);
+    // ACC_ADD_ILP returning atomics per thread are in flight before the first result is looked at (one at a time,
+    // the loop was eight serial round trips to L2: 6.5 us of a 43 us workgroup)
+    for (uint32_t i0 = tid; i0 < CELLS; i0 += blockDim.x * ACC_ADD_ILP) {
+        u64 old[ACC_ADD_ILP];
+        uint32_t big = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < ACC_ADD_ILP; ++k) {
+            const uint32_t i = i0 + k * blockDim.x;
+            old[k] = 0ull;
+            if (i < CELLS) {
+                const u64 v = tile[i];
+                const uint32_t px = tx * TW + (i & (TW - 1u)), py = ty * FL_TILE_H + (i >> TWL);
+                if (v != 0ull && px < astride && py < aheight) {
+                    // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
+                    // most `nparts` adds per launch (one per workgroup of its tile) onto a flushed cell,
+                    // so chunks below 1024/nparts hits are safe; larger ones go straight to the floats.
+                    if ((uint32_t)(v >> 54) >= 1024u / nparts) big |= 1u << k;
+                    else                                         // (as asm: the compiler waits for every returning atomic at the end of its branch)
+                        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "+v"(old[k]) : "v"(atom + py * astride + px), "v"(v) : "memory");
+                }
+            }
+        }
+        static_assert(ACC_ADD_ILP == 8 || ACC_ADD_ILP == 4, "the wait below names every result");
+        if constexpr (ACC_ADD_ILP == 8)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]) :: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < ACC_ADD_ILP; ++k) {
+            const bool full = (uint32_t)(old[k] >> 32) >= (256u << 23);
+            if (full || ((big >> k) & 1u)) {                      // rare: the cell is looked up again
+                const uint32_t i = i0 + k * blockDim.x;
+                const uint32_t gi = (ty * FL_TILE_H + (i >> TWL)) * astride + tx * TW + (i & (TW - 1u));
+                if (full) {
+                    const u64 cur = __hip_atomic_exchange(atom + gi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(cur >> 32) != 0u) spill_cell(cur, gi, out4);
+                } else
+                    spill_cell(tile[i], gi, out4);
             }
         }
     }
+#endif
+#ifdef ACC_X_TIMES
+    __syncthreads();
+    if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -272,6 +340,7 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
     // LDS: the tile, 64 marks per wave, and as many palette rows (2 KB each) as the slot range of one
     // workgroup touches — capped by what lets two narrow workgroups (one wide) share a CU's 160 KB
     const uint32_t spr = nslots / FL_PAL_H, slots_per_part = (nslots + nparts - 1) / nparts;
+    if (batch_records > 65536u) abort();        // directory words hold 16-bit counts; the kernel's marks 24 bits of 64 * batch_records
     const uint32_t want = (slots_per_part + spr - 1) / spr + 1;
     if (wide) {
         const uint32_t rows = want < 2u ? 2u : want > 12u ? 12u : want;
@@ -282,7 +351,7 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
                            log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows);
         return;
     }
-    const uint32_t rows = want < 2u ? 2u : want > 5u ? 5u : want;
+    const uint32_t rows = want < 2u ? 2u : want > (uint32_t)ACC_ROWS_MAX ? (uint32_t)ACC_ROWS_MAX : want;
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
     hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
