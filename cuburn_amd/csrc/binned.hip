@@ -27,7 +27,10 @@ __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restri
 }
 
 // Sum of the packed values of the lanes in `grp`, spilled to the float accumulator by the group's first lane
-__device__ __attribute__((noinline)) void hot_group(u64 v, unsigned long long grp, uint32_t gi, float *__restrict__ out4)
+#ifndef HOT_GROUP_INLINE
+#define HOT_GROUP_INLINE __forceinline__      /* a real call in the record loop keeps everything that lives across it in the few callee-saved VGPRs: spills */
+#endif
+__device__ HOT_GROUP_INLINE void hot_group(u64 v, unsigned long long grp, uint32_t gi, float *__restrict__ out4)
 {
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) {
@@ -70,7 +73,13 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #define ACC_ILP_WIDE 4     /* records per lane in flight, 256x64 tiles (one 16-wave workgroup per CU) */
 #endif
 #ifndef ACC_ILP
-#define ACC_ILP 4
+#define ACC_ILP 3          /* records per lane and step, 128x64 tiles: two steps are in flight (ACC_PIPE), and four per step do not fit 64 VGPRs without spills */
+#endif
+#ifndef ACC_GATHER_AHEAD
+#define ACC_GATHER_AHEAD 4     /* palette entries requested this many records ahead of their add (4: all of a step's at once; fewer: fewer VGPRs) */
+#endif
+#ifndef ACC_PIPE
+#define ACC_PIPE 1             /* the next step's record loads are in flight while the current step's records are added */
 #endif
 #ifndef ACC_ADD_ILP
 #define ACC_ADD_ILP 8          /* returning global atomics in flight per thread when the tile is added to the accumulator */
@@ -100,7 +109,7 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_acc_times(unsigne
 // 8 waves per SIMD only up to 80 SGPRs per wave (measured: tools/occupancy_probe.hip,
 // profiles/r03_occupancy_probe.txt; the compiler's table and the occupancy API say 96)
 template <uint32_t TWL>
-__global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024, TWL == 7u ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
@@ -133,7 +142,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const uint32_t *drow = dir + (size_t)bin * nbatch_total;
     const uint32_t per_slot = nbatch_total / nslots;
     const uint32_t spr = nslots / FL_PAL_H;                       // slots per palette row
-    const float inv_spr = 1.0f / (float)spr, inv_ps = 1.0f / (float)per_slot;
+    // (wave-uniform, but computed by the vector ALU: moved to scalar registers so that they do not hold two VGPRs through the loops)
+    const float inv_spr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)spr)));
+    const float inv_ps = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)per_slot)));
     const uint32_t chunk_slots = (rows_cap - 1u) * spr;
 
     if (b_lo >= b_hi) return;                                      // no batches for this part (tiny launches): nothing to add
@@ -191,9 +202,12 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         const uint32_t mark_l = ((lane * batch_records + first - excl + 1u) << 8) | (row_l & 255u);
         const unsigned char *gbase = reinterpret_cast<const unsigned char *>(log + (size_t)g0 * batch_records) - 4;   // (the marks' "1 +")
         uint32_t carry = 0;
-        for (uint32_t v0 = 0; v0 < total; v0 += 64 * ILP) {
-            uint32_t rec[ILP], poff[ILP];                           // poff: the mark (its low byte is the palette row)
-            bool live[ILP];
+        // One step = 64 * ILP records: `fetch` finds every record's run and requests it, `process` adds the records to
+        // the tile.  The record loads are issued from inline asm so that the NEXT step's requests can be in flight while
+        // this step's records go through the palette and the tile (ACC_PIPE): the compiler would wait for them at once.
+        // A step's results are its ILP records and one word with the ILP palette rows (one byte each).
+        static_assert(ILP >= 2 && ILP <= 4, "up to four rows to a word");
+        auto fetch = [&](const uint32_t v0, uint32_t (&rec)[ILP], uint32_t &rows) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
                 const uint32_t lo = v0 + k * 64, v = lo + lane;
@@ -205,32 +219,43 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 m = wave_incl_maxscan(m);
                 m = max(m, carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
-                live[k] = v < total;
-                rec[k] = 0u; poff[k] = 0u;
-                if (live[k]) {
+                // byte k of `rows` = the mark's low byte
+                rows = __builtin_amdgcn_perm(m, rows, k == 0 ? 0x03020104u : k == 1 ? 0x03020400u : k == 2 ? 0x03040100u : 0x04020100u);
 #ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
-                    rec[k] = ((m * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u));
+                rec[k] = ((m * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u));
 #elif FL_REC_BYTES == 3
-                    // 3-byte records: the two aligned words around the record's byte address in ONE 8-byte load (needs 4-byte
-                    // alignment only), the record cut out with v_alignbyte — an unaligned 4-byte load measured +31 %
+                // 3-byte records: the two aligned words around the record's byte address in ONE 8-byte load (needs 4-byte
+                // alignment only), the record cut out with v_alignbyte — an unaligned 4-byte load measured +31 %
+                rec[k] = 0u;
+                if (v < total) {
                     const size_t ba = ((size_t)g0 * batch_records + (v + (m >> 8) - 1u)) * 3u;
                     struct __attribute__((packed, aligned(4))) W2 { uint32_t lo, hi; };
                     const W2 w = *reinterpret_cast<const W2 *>(reinterpret_cast<const unsigned char *>(log) + (ba & ~(size_t)3));
                     rec[k] = __builtin_amdgcn_alignbyte(w.hi, w.lo, (uint32_t)ba & 3u) & 0xffffffu;
-#else
-                    // scalar base + 32-bit byte offset (at most 4 * 65 * batch_records)
-                    rec[k] = *reinterpret_cast<const uint32_t *>(gbase + (size_t)(uint32_t)(((m >> 8) + v) << 2));
-#endif
-                    poff[k] = m;
                 }
-            }
-            u64 val[ILP];
-#pragma unroll
-#ifdef ACC_X_NOPAL
-            for (int k = 0; k < ILP; ++k) val[k] = (1ull << 54) | (poff[k] & 0xffu) | (rec[k] & 0xffu);
 #else
-            for (int k = 0; k < ILP; ++k) val[k] = pal[__builtin_amdgcn_perm(poff[k], rec[k], 0x0c0c0400u)];      // (row << 8) | colour byte: FL_PAL_W == 256
+                // scalar base + 32-bit byte offset (at most 4 * 65 * batch_records); positions past the end of the
+                // virtual array read the group's first record (and are not used)
+                const uint32_t voff = v < total ? ((m >> 8) + v) << 2 : 4u;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
 #endif
+            }
+        };
+        auto process = [&](const uint32_t v0, uint32_t (&rec)[ILP], const uint32_t rows) __attribute__((always_inline)) {
+            bool live[ILP];
+            u64 val[ILP];
+            auto gather = [&](const int k) __attribute__((always_inline)) {
+#ifdef ACC_X_NOPAL
+                val[k] = (1ull << 54) | (rows & 0xffu) | (rec[k] & 0xffu);
+#else
+                val[k] = pal[__builtin_amdgcn_perm(rows, rec[k], 0x0c0c0000u | ((4u + k) << 8))];      // (row << 8) | colour byte: FL_PAL_W == 256
+#endif
+            };
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                live[k] = v0 + k * 64 + lane < total;
+                if (k < ACC_GATHER_AHEAD) gather(k);
+            }
             // A cell that takes most of the samples (a point attractor takes all of them) would receive
             // thousands of adds between the moment its count passes the drain threshold and the moment
             // the drain executes — enough to carry out of the 10-bit count.  When at least 48 lanes of the
@@ -241,6 +266,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
             {
                 const uint32_t o0 = rec[0] >> 8;
                 if (__builtin_expect(__popcll(__ballot(live[0] && o0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)o0))) >= 48, 0)) {
+#pragma unroll
+                    for (int k = ACC_GATHER_AHEAD; k < ILP; ++k) gather(k);          // (the rare path looks at every record's entry)
 #pragma unroll
                     for (int k = 0; k < ILP; ++k) {
                         const uint32_t off = rec[k] >> 8;
@@ -257,6 +284,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
                 const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
+                if (k + ACC_GATHER_AHEAD < ILP) gather(k + ACC_GATHER_AHEAD);           // palette entries are requested ACC_GATHER_AHEAD records ahead of their add
                 if (!live[k]) continue;
 #ifdef ACC_X_NOATOM
                 const u64 old = tile[off ^ 1u]; if (val[k] == 0x1234567ull) tile[off] = old;
@@ -271,7 +299,41 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                     }
                 }
             }
+        };
+        // the wait names the records it is for: nothing of `process` can be scheduled above it
+#define ACC_WAIT(n, r) do { if constexpr (ILP == 4) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[ILP - 2]), "+v"(r[ILP - 1]) :: "memory"); \
+                            else if constexpr (ILP == 3) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[ILP - 1]) :: "memory"); \
+                            else asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]) :: "memory"); } while (0)
+#define ACC_WAIT_NEWER(r) do { if constexpr (ILP == 4) ACC_WAIT(4, r); else if constexpr (ILP == 3) ACC_WAIT(3, r); else ACC_WAIT(2, r); } while (0)       /* all but the ILP newest loads */
+        constexpr uint32_t STEP = 64 * ILP;
+#if ACC_PIPE && !defined(ACC_X_NOLOG) && FL_REC_BYTES == 4
+        // Two sets of results alternate (A, B): while one set's records are added, the other's are on their way.  Each
+        // set has ONE place where it is requested, and B's processing trails into the next iteration: a second place
+        // (a prologue, say) would make the compiler merge two definitions, i.e. copy registers whose loads are still
+        // in flight (tools/check_asm_atomics.py looks for exactly that in the assembly).
+        uint32_t recA[ILP] = {}, recB[ILP] = {}, rowsA = 0u, rowsB = 0u;
+        for (uint32_t v0 = 0; v0 < total; v0 += 2 * STEP) {
+            fetch(v0, recA, rowsA);
+            if (v0 != 0u) { ACC_WAIT_NEWER(recB); process(v0 - STEP, recB, rowsB); }       // B is older than A: A stays in flight
+            if (v0 + STEP < total) { fetch(v0 + STEP, recB, rowsB); ACC_WAIT_NEWER(recA); } else ACC_WAIT(0, recA);
+            process(v0, recA, rowsA);
         }
+        if (((total + STEP - 1u) / STEP & 1u) == 0u && total != 0u) {                     // an even number of steps: the last B
+            ACC_WAIT(0, recB);
+            process((total - 1u) / STEP * STEP, recB, rowsB);
+        }
+#else
+        for (uint32_t v0 = 0; v0 < total; v0 += STEP) {
+            uint32_t rec[ILP], rows = 0u;
+            fetch(v0, rec, rows);
+#if !defined(ACC_X_NOLOG) && FL_REC_BYTES == 4
+            ACC_WAIT(0, rec);
+#endif
+            process(v0, rec, rows);
+        }
+#endif
+#undef ACC_WAIT
+#undef ACC_WAIT_NEWER
     }
     cb = ce;
     }

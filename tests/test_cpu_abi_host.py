@@ -235,3 +235,30 @@ def test_per_genome_kernel_compiles(built, cfg):
         if rc == _lib.FL_E_UNSUPPORTED:
             pytest.skip('libhiprtc is not installed')
         assert rc == 0, log.value.decode()[:3000]
+
+
+def test_asm_issued_loads_are_not_touched_in_flight(tmp_path):
+    """k_accum_tiles issues its record loads and the tile add's returning atomics from inline asm and
+    waits for them itself (binned.hip: ACC_PIPE, ACC_ADD_ILP), so the compiler does not know those
+    registers are in flight.  The device assembly of the shipped configuration is checked: no
+    instruction may read or write such a register between its load / atomic and the wait, and the
+    128x64 kernel must keep the budget that lets two workgroups share a CU (64 VGPRs, 80 SGPRs, no
+    scratch: profiles/r03_occupancy_probe.txt)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(REPO, 'cuburn_amd', 'csrc', 'binned.hip')
+    asm = str(tmp_path / 'binned.s')
+    r = subprocess.run([hipcc, '-O3', '-std=c++20', '--offload-arch=gfx950', '-ffp-contract=off', '--cuda-device-only',
+                        '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chk = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'check_asm_atomics.py'), asm], capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout[-2000:]
+    assert not chk.stdout.startswith('0 asm-issued'), chk.stdout
+    # resource usage of the narrow kernel, from the compiler's remarks
+    rem = r.stderr[r.stderr.index('k_accum_tilesILj7'):]
+    num = lambda key: int(re.search(key + r': (\d+)', rem).group(1))
+    assert num('VGPRs') <= 64 and num('TotalSGPRs') <= 80 and num(r'ScratchSize \[bytes/lane\]') == 0, rem[:1200]

@@ -41,3 +41,7 @@ st = np.sort(start)
 print('start times of workgroups 0, 100, 200, 255, 256, 300, 400, 511, 512, 600 (sorted by start): ' + ' '.join('%.1f' % st[i] for i in (0, 100, 200, 255, 256, 300, 400, 511, 512, 600)))
 ends = np.sort(a[:, 3] - t0)
 print('first ends: ' + ' '.join('%.1f' % e for e in ends[:6]))
+fast = np.argsort(dur)[:8]
+print('fastest workgroups (tile: zero / records / add us):', ', '.join('%d: %.1f / %.1f / %.1f' % (w // nparts, zero[w], recs[w], add[w]) for w in fast))
+q = np.percentile(recs, [1, 5, 10, 25, 50, 75])
+print('records phase percentiles 1/5/10/25/50/75 %%: ' + ' '.join('%.1f' % x for x in q))
