@@ -78,6 +78,9 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifndef ACC_GATHER_AHEAD
 #define ACC_GATHER_AHEAD 4     /* palette entries requested this many records ahead of their add (4: all of a step's at once; fewer: fewer VGPRs) */
 #endif
+#ifndef ACC_DIR_AHEAD
+#define ACC_DIR_AHEAD 1        /* a group's directory words are requested one group ahead (the first group's before the tile is zeroed) */
+#endif
 #ifndef ACC_PIPE
 #define ACC_PIPE 1             /* the next step's record loads are in flight while the current step's records are added */
 #endif
@@ -160,6 +163,11 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         const uint32_t i = tid + q * blockDim.x;
         stagev[q] = i < nrows * FL_PAL_W ? palette[row_lo * FL_PAL_W + i] : 0ull;
     }
+    // (so are the directory words of the wave's first group; every group then requests the next group's words
+    // before it walks its own records)
+#if ACC_DIR_AHEAD
+    uint32_t e_next = cb + wv * 64 + lane < ce ? drow[cb + wv * 64 + lane] : 0u;
+#endif
     if (cb == b_lo) {
         for (uint32_t i = tid; i < CELLS; i += blockDim.x) tile[i] = 0ull;
         mk[lane] = 0u;
@@ -181,7 +189,12 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         const uint32_t s0 = g0 / per_slot, rem0 = g0 - s0 * per_slot;
         // 64 directory entries per wave; their runs form one virtual array of `total` records
         const uint32_t batch = g0 + lane;
+#if ACC_DIR_AHEAD
+        const uint32_t e = e_next;
+        e_next = batch + nwaves * 64 < ce ? drow[batch + nwaves * 64] : 0u;
+#else
         const uint32_t e = batch < ce ? drow[batch] : 0u;
+#endif
         const uint32_t c = e & 0xffffu, first = e >> 16;
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
