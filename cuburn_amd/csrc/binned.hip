@@ -81,6 +81,9 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifndef ACC_DIR_AHEAD
 #define ACC_DIR_AHEAD 1        /* a group's directory words are requested one group ahead (the first group's before the tile is zeroed) */
 #endif
+#ifndef ACC_BYTE_MARKS
+#define ACC_BYTE_MARKS 1       /* run lookup: one LDS exchange of byte marks per step + ds_bpermute, instead of one exchange of word marks per 64 records */
+#endif
 #ifndef ACC_PIPE
 #define ACC_PIPE 1             /* the next step's record loads are in flight while the current step's records are added */
 #endif
@@ -99,6 +102,14 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifdef ACC_X_TIMES
 #define ACC_X_MAXWG 65536
 __device__ unsigned long long acc_wg_times[ACC_X_MAXWG][4];      // start, tile zeroed + first palette rows staged, records done, tile added
+// wave 0 of every workgroup also sums the shader clocks (s_memtime) it spends requesting a step's records (run lookup:
+// the mark exchange), waiting for a step's records, and adding them; [3] = the whole record phase, [4] = steps
+__device__ unsigned long long acc_wg_steps[ACC_X_MAXWG][5];
+extern "C" __attribute__((visibility("default"))) int fl_debug_acc_steps(unsigned long long *out, unsigned n)
+{
+    if (n > ACC_X_MAXWG) n = ACC_X_MAXWG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(acc_wg_steps), sizeof(unsigned long long) * 5 * n) == hipSuccess ? 0 : -1;
+}
 extern "C" __attribute__((visibility("default"))) int fl_debug_acc_times(unsigned long long *out, unsigned n)
 {
     if (n > ACC_X_MAXWG) n = ACC_X_MAXWG;
@@ -151,6 +162,10 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     const uint32_t chunk_slots = (rows_cap - 1u) * spr;
 
     if (b_lo >= b_hi) return;                                      // no batches for this part (tiny launches): nothing to add
+#ifdef ACC_X_TIMES
+    uint32_t x_fetch = 0, x_wait = 0, x_proc = 0, x_other = 0, x_steps = 0;
+    const uint32_t x_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     for (uint32_t cb = b_lo; cb < b_hi;) {
     const uint32_t cs_lo = cb / per_slot;
     const uint32_t ce = min(b_hi, (cs_lo + chunk_slots) * per_slot);
@@ -221,9 +236,35 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         // A step's results are its ILP records and one word with the ILP palette rows (one byte each).
         static_assert(ILP >= 2 && ILP <= 4, "up to four rows to a word");
         auto fetch = [&](const uint32_t v0, uint32_t (&rec)[ILP], uint32_t &rows) __attribute__((always_inline)) {
+#if ACC_BYTE_MARKS
+            // ONE exchange for the whole step: the runs that start inside it drop their lane number (+1) as a byte, every
+            // lane reads its ILP positions at once, the ILP max-scans are independent instruction chains (the wait states
+            // of one are filled by the others), and the marks themselves come from the runs' lanes by ds_bpermute —
+            // two waits on the LDS pipe per step instead of ILP.  (carry: the run number + 1 here, the mark below)
+            unsigned char *mk8 = reinterpret_cast<unsigned char *>(mk);
+            const bool starts = c != 0u && excl - v0 < 64u * ILP;
+            if (starts) mk8[excl - v0] = (unsigned char)(lane + 1u);
+            wave_sync();
+            uint32_t mm[ILP];
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) mm[k] = mk8[k * 64 + lane];
+            wave_sync();
+            if (starts) mk8[excl - v0] = 0;
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) mm[k] = wave_incl_maxscan(mm[k]);
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                mm[k] = max(mm[k], carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)mm[k], 63);
+                mm[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((mm[k] - 1u) << 2), (int)mark_l);
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
                 const uint32_t lo = v0 + k * 64, v = lo + lane;
+#if ACC_BYTE_MARKS
+                const uint32_t m = mm[k];
+#else
                 if (c != 0u && excl - lo < 64u) mk[excl - lo] = mark_l;
                 wave_sync();                 // lanes exchange data through LDS: without it the compiler
                 uint32_t m = mk[lane];       // forwards this lane's own earlier "= 0" into the load
@@ -232,6 +273,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 m = wave_incl_maxscan(m);
                 m = max(m, carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+#endif
                 // byte k of `rows` = the mark's low byte
                 rows = __builtin_amdgcn_perm(m, rows, k == 0 ? 0x03020104u : k == 1 ? 0x03020400u : k == 2 ? 0x03040100u : 0x04020100u);
 #ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
@@ -325,11 +367,20 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         // (a prologue, say) would make the compiler merge two definitions, i.e. copy registers whose loads are still
         // in flight (tools/check_asm_atomics.py looks for exactly that in the assembly).
         uint32_t recA[ILP] = {}, recB[ILP] = {}, rowsA = 0u, rowsB = 0u;
+#ifdef ACC_X_TIMES
+#define ACC_T(sum) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); sum += t_ - x_t; x_t = t_; } while (0)
+        uint32_t x_t = (uint32_t)__builtin_amdgcn_s_memtime();
+#else
+#define ACC_T(sum) do { } while (0)
+#endif
         for (uint32_t v0 = 0; v0 < total; v0 += 2 * STEP) {
-            fetch(v0, recA, rowsA);
-            if (v0 != 0u) { ACC_WAIT_NEWER(recB); process(v0 - STEP, recB, rowsB); }       // B is older than A: A stays in flight
-            if (v0 + STEP < total) { fetch(v0 + STEP, recB, rowsB); ACC_WAIT_NEWER(recA); } else ACC_WAIT(0, recA);
-            process(v0, recA, rowsA);
+            ACC_T(x_other); fetch(v0, recA, rowsA); ACC_T(x_fetch);
+            if (v0 != 0u) { ACC_WAIT_NEWER(recB); ACC_T(x_wait); process(v0 - STEP, recB, rowsB); ACC_T(x_proc); }       // B is older than A: A stays in flight
+            if (v0 + STEP < total) { fetch(v0 + STEP, recB, rowsB); ACC_T(x_fetch); ACC_WAIT_NEWER(recA); } else ACC_WAIT(0, recA);
+            ACC_T(x_wait); process(v0, recA, rowsA); ACC_T(x_proc);
+#ifdef ACC_X_TIMES
+            x_steps += v0 + STEP < total ? 2 : 1;
+#endif
         }
         if (((total + STEP - 1u) / STEP & 1u) == 0u && total != 0u) {                     // an even number of steps: the last B
             ACC_WAIT(0, recB);
@@ -346,6 +397,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         }
 #endif
 #undef ACC_WAIT
+#undef ACC_T
 #undef ACC_WAIT_NEWER
     }
     cb = ce;
@@ -355,6 +407,10 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     // add the tile to the global packed accumulator: one row segment of 64 cells per wave
     // instruction (coalesced atomics), draining cells that reach 512 hits
 #ifdef ACC_X_TIMES
+    if (tid == 0 && blockIdx.x < ACC_X_MAXWG) {
+        unsigned long long *o = acc_wg_steps[blockIdx.x];
+        o[0] = x_fetch; o[1] = x_wait; o[2] = x_proc; o[3] = (uint32_t)__builtin_amdgcn_s_memtime() - x_t0; o[4] = x_steps;
+    }
     __syncthreads();
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
 #endif

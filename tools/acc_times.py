@@ -45,3 +45,17 @@ fast = np.argsort(dur)[:8]
 print('fastest workgroups (tile: zero / records / add us):', ', '.join('%d: %.1f / %.1f / %.1f' % (w // nparts, zero[w], recs[w], add[w]) for w in fast))
 q = np.percentile(recs, [1, 5, 10, 25, 50, 75])
 print('records phase percentiles 1/5/10/25/50/75 %%: ' + ' '.join('%.1f' % x for x in q))
+# shader clocks wave 0 of each workgroup spends per step (library built after the step clocks were added)
+if hasattr(lib, 'fl_debug_acc_steps'):
+    o5 = (C.c_ulonglong * (5 * n))()
+    if lib.fl_debug_acc_steps(o5, n) == 0:
+        st5 = np.array(list(o5), dtype=np.float64).reshape(n, 5)
+        ok = st5[:, 4] > 0
+        tot = st5[ok].sum(0)
+        print('wave 0 of every workgroup, shader clocks per step of 64 x ILP records (mean over %d steps): run lookup + requests %.0f, waiting for the records %.0f, '
+              'palette + tile adds %.0f; per-group work outside the steps %.0f per step (record phase %.0f clocks per step in all)'
+              % (tot[4], tot[0] / tot[4], tot[1] / tot[4], tot[2] / tot[4], (tot[3] - tot[0] - tot[1] - tot[2]) / tot[4], tot[3] / tot[4]))
+        hot = np.argsort(-st5[:, 4])[:200]
+        t2 = st5[hot].sum(0)
+        print('  the 200 workgroups with most steps: lookup %.0f, wait %.0f, adds %.0f, outside %.0f clocks per step (%.1f steps per workgroup-wave)'
+              % (t2[0] / t2[4], t2[1] / t2[4], t2[2] / t2[4], (t2[3] - t2[0] - t2[1] - t2[2]) / t2[4], t2[4] / 200))
