@@ -19,6 +19,8 @@ n = ntiles * nparts
 out = (C.c_ulonglong * (4 * n))()
 assert lib.fl_debug_acc_times(out, n) == 0
 a = np.array(list(out), dtype=np.float64).reshape(n, 4) / 100.0          # us
+a = a[a[:, 0] > a[:, 0].max() - 2000.0]                                    # (entries of workgroups without work in the last launch are stale)
+n = len(a)
 t0 = a[:, 0].min()
 start = a[:, 0] - t0
 zero, recs, add = a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2]
@@ -28,15 +30,16 @@ print('workgroups %d: span %.1f us; sum of run times / 512 slots = %.1f us (%.0f
 print('per workgroup (mean / median / p90 / max us): zero tile + stage palette %.1f / %.1f / %.1f / %.1f; records %.1f / %.1f / %.1f / %.1f; add tile to the global cells %.1f / %.1f / %.1f / %.1f'
       % (zero.mean(), np.median(zero), np.percentile(zero, 90), zero.max(), recs.mean(), np.median(recs), np.percentile(recs, 90), recs.max(),
          add.mean(), np.median(add), np.percentile(add, 90), add.max()))
-per_tile = dur.reshape(ntiles, nparts).mean(1)
+uniform = n == ntiles * nparts
+per_tile = dur.reshape(ntiles, nparts).mean(1) if uniform else dur[:ntiles]
 order = np.argsort(-per_tile)
-print('slowest tiles (tile: mean run time of its 16 workgroups, first start):', ', '.join('%d: %.0f us @%.0f' % (t, per_tile[t], start.reshape(ntiles, nparts)[t].min()) for t in order[:8]))
+if uniform: print('slowest tiles (tile: mean run time of its 16 workgroups, first start):', ', '.join('%d: %.0f us @%.0f' % (t, per_tile[t], start.reshape(ntiles, nparts)[t].min()) for t in order[:8]))
 late = np.argsort(-(a[:, 3] - t0))[:6]
 print('last to finish (workgroup: tile, start, run):', ', '.join('%d: tile %d @%.0f +%.0f' % (w, w // nparts, start[w], dur[w]) for w in late))
 busy = np.zeros(int(span) + 2)
 for s0, d0 in zip(start, dur):
     busy[int(s0):int(s0 + d0) + 1] += 1
-print('workgroups in flight over time (every 40 us):', ' '.join('%d' % busy[i] for i in range(0, int(span), 40)))
+print('workgroups in flight over time (every 40 us):', ' '.join('%d' % busy[i] for i in range(0, min(int(span), 2000), 40)))
 st = np.sort(start)
 print('start times of workgroups 0, 100, 200, 255, 256, 300, 400, 511, 512, 600 (sorted by start): ' + ' '.join('%.1f' % st[i] for i in (0, 100, 200, 255, 256, 300, 400, 511, 512, 600)))
 ends = np.sort(a[:, 3] - t0)
