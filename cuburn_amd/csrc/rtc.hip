@@ -132,7 +132,19 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #endif
                           "-fno-slp-vectorize",
     };
-    const hiprtcResult rc = a.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
+    // FLAME_RTC_FLAGS="-mllvm -x=y ...": extra options for code-generation experiments (tools/exp_rtc_flags.sh)
+    std::vector<const char *> optv(opts, opts + sizeof opts / sizeof *opts);
+    std::vector<std::string> extra;
+    if (const char *e = getenv("FLAME_RTC_FLAGS")) {
+        std::string w;
+        for (const char *q = e;; ++q) {
+            if (*q && *q != ' ') { w += *q; continue; }
+            if (!w.empty()) { extra.push_back(w); w.clear(); }
+            if (!*q) break;
+        }
+        for (const std::string &x : extra) optv.push_back(x.c_str());
+    }
+    const hiprtcResult rc = a.compile(prog, (int)optv.size(), optv.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         a.log_size(prog, &n);
