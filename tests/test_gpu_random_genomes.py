@@ -169,7 +169,7 @@ def _blocks16(a, dim):
 # linear, block L1 0.11 at fuse 64, 0.010 at 256).  Everything here runs at RenderManager's DEFAULTS,
 # through queue_frame: no explicit fuse, production slots.  The CPU sample uses 64 trajectories (eight
 # trajectories of a map that does not mix are not a distribution).
-@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102, 110, 176])
+@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102, 110, 176, 226])
 def test_single_xform_genome_default_schedule(seed):
     gnm, prof = random_genome(seed)
     assert len(gnm['xforms']) == 1
@@ -186,7 +186,10 @@ def test_single_xform_genome_default_schedule(seed):
     nrun = m.last_nsamples
     F = prepare(gnm, prof, tc, nslots=m.fb.nslots)
     n = 2 ** 26
-    refh, _, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, 64)
+    # (seed 226 — handkerchief + perspective + rings2, from the soak of seeds 221-260 — mixes even less: block L1 0.20
+    # against 8 trajectories, 0.049 against 64, 0.033 against 512, 0.0235 against 4096 and below the bar against 65536
+    # trajectories of 1024 iterations, i.e. against a CPU sample made the way the GPU's is: many short orbits)
+    refh, _, _ = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], n, 65536 if seed == 226 else 64)
     refd = refh.astype(np.float64)[:, 3]
     fg, fr = dens.sum() / nrun, refd.sum() / n
     assert abs(fg - fr) < 0.005 + 0.01 * fr, (fg, fr)
