@@ -9,9 +9,14 @@
 // profiles/r01_atomic_microbench*.txt).  Cells that fill up (>= 512 hits) are drained into the
 // float accumulator exactly as in the direct path (cuburn/code/iter.py:366-406).
 //
-// The kernel is latency bound (directory -> record -> palette -> LDS atomic is a dependent
-// chain), so: 64 KB tiles (two 1024-thread workgroups = 32 waves per CU) and four independent
-// records per lane in flight.
+// The kernel is latency bound (directory -> run lookup -> record -> palette -> LDS atomic is a
+// dependent chain per wave, the records come from HBM ~2400 clocks after they are asked for), so:
+// 64 KB tiles (two 1024-thread workgroups = 32 waves per CU: 64 VGPRs and — measured — 80 SGPRs per
+// wave at most), and a wave walks its runs in steps of 3 x 64 records, two steps in flight: the
+// record loads are issued from inline asm and waited for with partial s_waitcnt, so that step n+1
+// is on its way while step n goes through the palette and the tile (tools/check_asm_atomics.py
+// checks the assembly for what the compiler cannot know about those registers; DESIGN.md 4.1
+// "Round 3 (second half)" has the measurements behind every piece of this).
 #include "flame_device.h"
 #include "kernels.h"
 
