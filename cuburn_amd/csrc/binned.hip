@@ -89,6 +89,9 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #ifndef ACC_BYTE_MARKS
 #define ACC_BYTE_MARKS 1       /* run lookup: one LDS exchange of byte marks per step + ds_bpermute, instead of one exchange of word marks per 64 records */
 #endif
+#ifndef ACC_LOAD_MOD
+#define ACC_LOAD_MOD ""        /* cache policy of the record loads (" nt", " sc1", ...): experiment, see profiles/r03_accum_cache_policy.txt */
+#endif
 #ifndef ACC_PIPE
 #define ACC_PIPE 1             /* the next step's record loads are in flight while the current step's records are added */
 #endif
@@ -297,7 +300,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 // scalar base + 32-bit byte offset (at most 4 * 65 * batch_records); positions past the end of the
                 // virtual array read the group's first record (and are not used)
                 const uint32_t voff = v < total ? ((m >> 8) + v) << 2 : 4u;
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
+                asm volatile("global_load_dword %0, %1, %2" ACC_LOAD_MOD : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
 #endif
             }
         };

@@ -37,6 +37,9 @@
 #ifndef FL_CNT_SETS
 #define FL_CNT_SETS 3          /* sets of tile counters per 4-wave workgroup (LDS: an array of tiles + 1 words each) */
 #endif
+#ifndef FL_LOG_NT
+#define FL_LOG_NT 1          /* the sample log leaves with non-temporal stores: written once, read by k_accum_tiles much later (k_accum_tiles 380 -> 347 us, k_iter unchanged) */
+#endif
 #ifndef FL_ITER_ROT3
 #define FL_ITER_ROT3 1
 #endif
@@ -467,7 +470,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 #pragma unroll
                                 for (int t = 0; t < SETS; ++t) { cnt[t * CNTW + b] = at; at += vs[t]; }
                             }
-                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;      // (plain stores: non-temporal ones here cost k_iter +60 %)
                             if (b == bg.nbins) *s_nvalid = excl;
                             running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         }
@@ -499,7 +502,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                             uint32_t at = excl;
 #pragma unroll
                             for (int t = 0; t < SETS; ++t) { cnt[t * CNTW + b] = at; at += vs[t]; }
-                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;
+                            if (b < bg.nbins) bin_dir[(size_t)b * bg.nbatch_total + batch_id] = (excl << 16) | v;      // (plain stores: non-temporal ones here cost k_iter +60 %)
                             else *s_nvalid = excl;
                         }
                     }
@@ -538,7 +541,16 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 }
 #else
                 uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
+#if FL_LOG_NT      /* the log is written once and read by another kernel much later */
+                {
+                    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ *s4 = reinterpret_cast<const u32x4_ *>(stage);
+                    u32x4_ *d4 = reinterpret_cast<u32x4_ *>(dst);
+                    for (uint32_t i = tid; i * 4 < nvalid; i += NT) __builtin_nontemporal_store(s4[i], d4 + i);
+                }
+#else
                 for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
+#endif
 #endif
                 for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
                 ++batch_in_slot;
