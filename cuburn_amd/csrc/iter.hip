@@ -37,6 +37,9 @@
 #ifndef FL_CNT_SETS
 #define FL_CNT_SETS 3          /* sets of tile counters per 4-wave workgroup (LDS: an array of tiles + 1 words each) */
 #endif
+#ifndef FL_ITER_PRIO
+#define FL_ITER_PRIO 2         /* wave priority of the walk part of a round (0: no priority changes) */
+#endif
 #ifndef FL_LOG_NT
 #define FL_LOG_NT 1          /* the sample log leaves with non-temporal stores: written once, read by k_accum_tiles much later (k_accum_tiles 380 -> 347 us, k_iter unchanged) */
 #endif
@@ -301,6 +304,15 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
     uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
     auto advance = [&](const uint32_t dst) __attribute__((always_inline)) {
+        // Wave priority: the walk — everything up to the swap's barrier and the reads behind it — runs at a raised
+        // priority, the plotting that follows at the normal one.  A SIMD holds one wave of each of six workgroups; the
+        // wave whose three siblings (on the other SIMDs) already wait at the round's barrier should not queue behind
+        // waves that are packing records: k_iter_spec 672 -> 632 us ALONE (level 1, 2 or 3: the same; lowering it later, or
+        // raising it only for the swap, gains less: profiles/r03_wave_priority.txt).  In the two-lane frame loop the other
+        // lane's kernels already fill those issue slots: the frame time does not move; a single frame gains the 6 %.
+#if FL_ITER_PRIO
+        __builtin_amdgcn_s_setprio(FL_ITER_PRIO);
+#endif
         if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);      // iter.py:225-229
 
         const int k_cur = k_next;
@@ -325,6 +337,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+#if FL_ITER_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             par ^= 1u;
         }
     };
