@@ -209,7 +209,9 @@ def main():
         return dry_run(args, rank, world)
 
     from cuburn_amd import configs
-    gnm, prof = configs.CONFIGS[args.config]()
+    # FLAME_BENCH_SAMPLES: another sample count for the chosen config (geometry experiments; the headline runs without it)
+    _ns = os.environ.get('FLAME_BENCH_SAMPLES')
+    gnm, prof = configs.CONFIGS[args.config](samples=float(_ns)) if _ns and args.config != 'cfg1' else configs.CONFIGS[args.config]()
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:          # before anything touches the GPU
         cpu = cpu_baseline(gnm, prof, args.cpu_seconds)
@@ -383,7 +385,7 @@ def main():
                                     '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out') if args.config == 'cfg2'
                        else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
                             % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
-                       'walker_waves': mgr.fb.nw,
+                       'walker_waves': mgr.fb.nw, 'walker_slots': mgr.fb.nslots,
                        'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round((acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps, 4),
                                         'note': 'the big kernels do not overlap usefully (DESIGN 4.1): the second lane hides copies, clears and launch gaps only'},
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
@@ -407,7 +409,10 @@ def main():
                                     'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
                                     'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
                          'k_accum_tiles_ms_per_frame': round(acc['accum_ms'] / ksteps, 4),
-                         'k_flush_ms_per_frame': round(acc['flush_only_ms'] / ksteps, 4)},
+                         'k_flush_ms_per_frame': round(acc['flush_only_ms'] / ksteps, 4),
+                         'note': ('kernel times: one stream lane, the frame loop\'s walker geometry (%d slots).  For frames of up to 2^28 samples the loop '
+                                  'runs 1024 slots: a third fewer un-plotted fuse iterations, the PIPELINE ~4 %% faster, this chain ALONE ~5 %% slower '
+                                  'than at 1536 slots (FLAME_NSLOTS=1536: 1.05 ms = 0.51; profiles/r03_slots_by_samples.txt)' % mgr.fb.nslots)},
             'de_filter': {'kernels': '8 x k_de_dir (the first normalises the accumulator, the last un-normalises and tone-maps)', 'ms_per_frame': round(de_s * 1e3, 4),
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,

@@ -92,6 +92,14 @@ class Framebuffers(object):
     # cfg5 8K: 97 -> 79 ms per frame; at 1080p the 4-wave geometry is 3 % faster).  Explicit
     # nslots / FLAME_NW pin the geometry.
     NARROW, WIDE, HUGE = (4, 1536), (8, 1024), (16, 1024)
+    # Small images with few samples per frame: 1024 slots (the reference's 1024 ring entries, util.py:343).  Every
+    # walker spends the reference's 256 un-plotted rounds per frame (render.py:214), so fewer walkers are less work:
+    # with up to 2^28 samples (one launch of <= 1024 rounds) the pipelined frame loop is 2.4-3.6 % faster (cfg2 1.44 ->
+    # 1.39 ms) although the iterate kernel ALONE is 12 % slower at four instead of six waves per SIMD — the other
+    # stream lane's kernels run beside it.  With more samples the second launch costs more than the fuse saves
+    # (profiles/r03_slots_by_samples.txt).  Decided when a context is first used for an image class, then kept.
+    NARROW_FEW = (4, 1024)
+    FEW_SAMPLES = 2 ** 28
     WIDE_FROM_TILES = 1024
     HUGE_FROM_TILES = 2047      # above 4K (where the accumulate switches to 256x64 tiles): 16-wave workgroups,
                                 # batches of 16384 samples (cfg5 8K: 59.1 -> 52.2 ms per frame)
@@ -101,6 +109,7 @@ class Framebuffers(object):
         env_nw = os.environ.get('FLAME_NW')
         self._auto = nslots is None and env_nw is None
         self._cfg = (int(env_nw) if env_nw in ('8', '16') else 4, nslots if nslots is not None else self.NARROW[1])
+        self._narrow = None                 # the small-image geometry in use once a frame's sample count has been seen
         self._ctx = None
         self.generation = 0                 # bumped whenever the native context is re-created
         self.nout = 65536                   # RNG states of the output dither kernel
@@ -144,11 +153,17 @@ class Framebuffers(object):
         ring.append(ring.pop(0))
         return ring[-1]
 
-    def set_dim(self, width, height, stream=None):
+    def set_dim(self, width, height, stream=None, nsamples=None):
         dim = self.calc_dim(width, height)
         if self._auto:
             ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
             want = self.HUGE if ntiles > self.HUGE_FROM_TILES else self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
+            if want == self.NARROW:
+                if self._narrow is None and nsamples is not None:       # first frame of this class: few samples -> fewer walkers
+                    self._narrow = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
+                want = self._narrow or (self._cfg if self._cfg in (self.NARROW, self.NARROW_FEW) else self.NARROW)
+            else:
+                self._narrow = None
             if want != self._cfg:
                 self._drop_ctx()
                 self._cfg = want
@@ -289,7 +304,7 @@ class RenderManager(object):
         ``dev_out`` / ``host``: see Output.copy (frame straight into a device buffer of the caller).
         """
         lib = _lib.load()
-        dim = self.fb.set_dim(gprof.width, gprof.height)
+        dim = self.fb.set_dim(gprof.width, gprof.height, nsamples=gprof.spp(tc) * gprof.width * gprof.height)
         td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
         ts = tc - 0.5 * td
         g = rdr._handle(self.fb)

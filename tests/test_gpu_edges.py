@@ -277,7 +277,8 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 
 def test_walker_geometry_follows_image_size():
-    """A manager built without an explicit slot count uses 1536 x 4-wave slots for small images,
+    """A manager built without an explicit slot count uses 4-wave slots for small images — 1024 of
+    them for frames of up to 2^28 samples, 1536 above, decided by the first frame of the class —
     1024 x 8-wave slots from ~1440p up and 1024 x 16-wave slots above 4K (the native context is
     re-created on the switch, genome handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)
@@ -288,7 +289,10 @@ def test_walker_geometry_follows_image_size():
     rdr_s, rdr_b = render.Renderer(gnm, small), render.Renderer(gnm, big)
     gen0 = m.fb.generation
     evt, a = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()
-    assert m.fb.generation == gen0 and np.array(a)[..., 3].max() > 0
+    assert (m.fb.nw, m.fb.nslots) == (4, 1024) and m.fb.generation == gen0 + 1 and np.array(a)[..., 3].max() > 0
+    gen0 += 1
+    evt, a1 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # decided once: no further switch
+    assert m.fb.generation == gen0
     evt, b = m.queue_frame(rdr_b, gnm, big, 0.5); evt.synchronize()
     assert (m.fb.nw, m.fb.nslots) == (16, 1024) and m.fb.generation == gen0 + 1
     b = np.array(b)
@@ -298,9 +302,17 @@ def test_walker_geometry_follows_image_size():
     evt, c = m.queue_frame(render.Renderer(gnm, mid), gnm, mid, 0.5); evt.synchronize()
     assert (m.fb.nw, m.fb.nslots) == (8, 1024) and m.fb.generation == gen0 + 2 and np.array(c)[..., 3].max() > 0
     evt, a2 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # same Renderer, new context
-    assert (m.fb.nw, m.fb.nslots) == (4, 1536) and m.fb.generation == gen0 + 3
+    assert (m.fb.nw, m.fb.nslots) == (4, 1024) and m.fb.generation == gen0 + 3
     a, a2 = np.array(a).astype(np.float64), np.array(a2).astype(np.float64)
     assert np.abs(a - a2).mean() < 6.0
+    # many samples per frame on a small image: the 1536-slot geometry the manager starts with stays
+    q = render.RenderManager(device=0, host_seed=5)
+    many = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
+    evt, _ = q.queue_frame(render.Renderer(gnm, many), gnm, many, 0.5); evt.synchronize()
+    assert (q.fb.nw, q.fb.nslots) == (4, 1536) and q.fb.generation == 0
+    evt, _ = q.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()          # (and is kept for later frames of the class)
+    assert (q.fb.nw, q.fb.nslots) == (4, 1536) and q.fb.generation == 0
+    q.fb.free()
     # an explicit slot count pins the geometry
     p = render.RenderManager(device=0, nslots=NSLOTS, host_seed=5)
     evt, _ = p.queue_frame(render.Renderer(gnm, big), gnm, big, 0.5); evt.synchronize()
