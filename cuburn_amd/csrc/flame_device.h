@@ -96,7 +96,9 @@ __device__ __forceinline__ uint32_t trunca(float f) {
 #define FL_MAX_BINS 2047u                      /* 128x64 tiles: tile number shares the 32-bit staged record */
 #define FL_TILE_W_WIDE_LOG2 8u                 /* 256x64 tiles for larger images (tile number staged separately) */
 #define FL_MAX_BINS_WIDE 8191u
+#ifndef FL_BIN_R_MAX
 #define FL_BIN_R_MAX 16          /* rounds per sorted batch (records a thread holds in registers) */
+#endif
 
 // XCD id of the executing workgroup (HW_REG_XCC_ID, bits [3:0])
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7; }

@@ -127,6 +127,9 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
                           "-DFL_CNT_SETS_BIG=" FL_STR(FL_CNT_SETS_BIG),
 #endif
                           "-DFL_REC_BYTES=" FL_STR(FL_REC_BYTES),
+#ifdef FL_BIN_R_MAX
+                          "-DFL_BIN_R_MAX=" FL_STR(FL_BIN_R_MAX),
+#endif
 #ifdef FL_ITER_ROT3
                           "-DFL_ITER_ROT3=" FL_STR(FL_ITER_ROT3),
 #endif
