@@ -262,24 +262,69 @@ def accumulator_tensor(fb, device, dim=None):
     return torch.as_tensor(_DeviceArray(p.value, nfloats), device=torch.device('cuda', device))
 
 
-# Rows of summed accumulator a band carries beyond its own rows on either side.  The chain's reach: 8 DE
-# directions x (15 taps + the 9 rows of the two density blurs at the outermost tap) = 192 rows; the tone filters
-# are per pixel.  A multiple of 16 (a band must be a valid accumulator height).
+# Rows of its input that one output row of a filter depends on, on either side (the reach of the chain is the sum
+# over the profile's filter order).  bilateral: 8 directions x (15 taps + the 9 rows of the two nested density
+# blurs at the outermost tap, cuburn/filters.py:62-95) = 192; haloclip: den_blur_1c on patterns 2 and 3 = 2 x 3
+# rows; smearclip: full_blur on patterns 2, 3, 0, 1 = 3 x 3 rows (pattern 0 is horizontal)
+# (cuburn/filters.py:118-170); everything else is per pixel.
+FILTER_REACH = {'bilateral': 8 * 24, 'haloclip': 6, 'smearclip': 9}
+# Rows of summed accumulator a band carries beyond its own rows on either side: a multiple of 16 (a band with its
+# halos must be a valid accumulator height), at least the reach of the profile's chain (checked per frame).
 BAND_HALO = 224
+
+
+def chain_reach(filter_names):
+    """Rows either side that the output of the filter chain ``filter_names`` depends on."""
+    return sum(FILTER_REACH.get(n, 0) for n in filter_names)
 
 
 def band_plan(ah, world, halo=BAND_HALO):
     """
     Row bands of an accumulator of ``ah`` rows for ``world`` ranks: ``(rows_per, [(r0, r1)] per rank)`` with
-    every r0 / r1 a multiple of 16 and equal ``rows_per`` (what reduce-scatter needs; the last bands may be
-    short or empty), or None when bands make no sense (one rank, or a band shorter than its halo).
+    every r0 / r1 a multiple of 16 and equal ``rows_per`` (what reduce-scatter needs; the last band may be
+    short), or None when bands make no sense: one rank, a band shorter than its halo, or a rank that would be
+    left without rows (the callers then all-reduce and filter the whole frame everywhere).
     """
     if world < 2:
         return None
     rows_per = 16 * -(-ah // (16 * world))
-    if rows_per < halo:
+    if rows_per < halo or (world - 1) * rows_per >= ah:
         return None
-    return rows_per, [(min(r * rows_per, ah), min((r + 1) * rows_per, ah)) for r in range(world)]
+    return rows_per, [(r * rows_per, min((r + 1) * rows_per, ah)) for r in range(world)]
+
+
+def band_path_ok(out, dim, filter_names, halo=BAND_HALO):
+    """
+    Row bands need an interleaved 8 / 16-bit frame (a band's rows are a slice of the frame: the encoders' planar
+    formats, shape (3, h, w), are not) and a halo that covers the reach of THIS profile's filter chain; anything
+    else takes the all-reduce path, where every rank filters and converts the whole frame.
+    """
+    interleaved = out.dtype in ('u1', 'u2') and tuple(out.shape(dim)) == (dim.h, dim.w, 4)
+    return bool(interleaved and chain_reach(filter_names) <= halo)
+
+
+def halo_plan(plan, rank, ah, halo=BAND_HALO):
+    """
+    What ``rank`` sends and receives in the halo exchange that follows the reduce-scatter — a pure function of
+    the band plan, so that every (sender, receiver) pair can be checked without a process group.  Returns
+    ``dict(top, bot, sends, recvs)``: ``top`` / ``bot`` = halo rows received above / below the band (0 at the
+    image's own edges; the band below may be the short last one, which then sends what it has);
+    ``sends`` = [(peer, first row within this rank's band, rows)], ``recvs`` = [(peer, 'top' | 'bot', rows)],
+    both in the order up, down.
+    """
+    rows_per, bands = plan
+    r0, r1 = bands[rank]
+    n = r1 - r0
+    top = halo if r0 > 0 else 0
+    bot = min(halo, ah - r1)
+    sends, recvs = [], []
+    if top:                                     # the band above always has rows_per >= halo rows
+        sends.append((rank - 1, 0, min(halo, n)))
+        recvs.append((rank - 1, 'top', top))
+    if bot:                                     # only a full band has a band below it
+        sends.append((rank + 1, n - halo, halo))
+        recvs.append((rank + 1, 'bot', bot))
+    return dict(top=top, bot=bot, sends=sends, recvs=recvs)
 
 
 def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO):
@@ -287,8 +332,9 @@ def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO):
     ``acc2d``: this rank's accumulator as a (ah, row_floats) tensor.  Sums it over the ranks by bands and
     returns ``(band, top)``: the summed rows ``[r0 - top, r1 + bottom)`` of this rank's band with its
     halos (``top`` / ``bottom`` = halo, or 0 at the image's own edges), as a new tensor.
-    Collective: every rank calls it.  RCCL: one reduce-scatter + two neighbour exchanges; gloo (CPU
-    tests) has no reduce-scatter: all-reduce, then the same slicing.
+    Collective: every rank calls it.  One reduce-scatter (gloo, the CPU tests' backend, has none: all-reduce and
+    keep the own band) followed by the neighbour exchange of ``halo_plan`` — the same isend / irecv code on
+    both backends.
     """
     rows_per, bands = plan
     ah, rowf = acc2d.shape
@@ -301,27 +347,18 @@ def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO):
         core = torch.empty((rows_per, rowf), dtype=acc2d.dtype, device=acc2d.device)
         dist.reduce_scatter_tensor(core, padded, op=dist.ReduceOp.SUM)
         core = core[:r1 - r0]
-        # halos: the neighbours' outermost summed rows (bands are at least `halo` rows tall, except
-        # possibly the last non-empty one, which then sends what it has)
-        up, down = rank - 1, rank + 1
-        top = torch.empty((halo if r0 > 0 else 0, rowf), dtype=acc2d.dtype, device=acc2d.device)
-        nbot = min(halo, max(ah - r1, 0))
-        bot = torch.empty((nbot, rowf), dtype=acc2d.dtype, device=acc2d.device)
-        ops = []
-        if r1 > r0:
-            if r0 > 0:
-                ops.append(dist.P2POp(dist.isend, core[:halo].contiguous(), up))
-                ops.append(dist.P2POp(dist.irecv, top, up))
-            if nbot > 0:
-                ops.append(dist.P2POp(dist.isend, core[-halo:].contiguous(), down))
-                ops.append(dist.P2POp(dist.irecv, bot, down))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return torch.cat([top, core, bot]), top.shape[0]
-    dist.all_reduce(acc2d, op=dist.ReduceOp.SUM)
-    top = halo if r0 > 0 else 0
-    return acc2d[r0 - top:min(r1 + halo, ah)].clone(), top
+    else:
+        dist.all_reduce(acc2d, op=dist.ReduceOp.SUM)
+        core = acc2d[r0:r1]
+    hp = halo_plan(plan, rank, ah, halo)
+    bufs = dict(top=torch.empty((hp['top'], rowf), dtype=acc2d.dtype, device=acc2d.device),
+                bot=torch.empty((hp['bot'], rowf), dtype=acc2d.dtype, device=acc2d.device))
+    ops = [dist.P2POp(dist.isend, core[first:first + rows].contiguous(), peer) for peer, first, rows in hp['sends']]
+    ops += [dist.P2POp(dist.irecv, bufs[side], peer) for peer, side, rows in hp['recvs']]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return torch.cat([bufs['top'], core, bufs['bot']]), hp['top']
 
 
 def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
@@ -354,6 +391,30 @@ def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
     return out, bdim
 
 
+class TorchFrameEvent(object):
+    """
+    Completion handle of a frame whose last step ran on torch's stream (the band path's all-gather and D2H copy):
+    the interface of render.DurationEvent (cuburn/render.py:26-38) on a pair of torch events.  ``keep`` holds the
+    tensors the asynchronous copy still reads.
+    """
+
+    def __init__(self, start, end, keep=None):
+        self._start, self._end, self._keep, self._ms = start, end, keep, None
+
+    def synchronize(self):
+        if self._ms is None:
+            self._end.synchronize()
+            self._ms = self._start.elapsed_time(self._end)
+            self._keep = None
+        return self
+
+    def query(self):
+        return self._ms is not None or self._end.query()
+
+    def time(self):
+        return self.synchronize()._ms
+
+
 def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=True):
     """
     RenderManager.queue_frame for ONE frame split by samples over all ranks.  Every rank must
@@ -382,30 +443,33 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=
     _lib.check(lib.fl_iterate(fb.ctx, g, dim.w, dim.h, float(nsamps), mgr.fuse,
                               mgr.resolve_accum_mode(dim), C.byref(run)))
     mgr.last_nsamples = run.value
-    plan = band_plan(dim.ah, world) if (bands and rdr.out.dtype in ('u1', 'u2') and len(rdr.out.shape(dim)) == 3) else None
+    plan = band_plan(dim.ah, world) if (bands and band_path_ok(rdr.out, dim, [f.name for f in rdr.filts])) else None
     if world > 1 and plan is not None:
         # row bands: reduce-scatter + halo exchange, filter and convert the band, all-gather the 8-bit rows
+        t_start = torch.cuda.Event(enable_timing=True)
+        t_start.record()
         acc = accumulator_tensor(fb, device, dim).view(dim.ah, dim.astride * 4)      # waits for the iterate + flush kernels
         band, top = exchange_bands(acc, plan, rank, world)
         rows_per, ranges = plan
         r0, r1 = ranges[rank]
         g = fb.gutter
         mine = torch.zeros((rows_per, dim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=acc.device)
-        if r1 > r0:
-            out, bdim = filter_band(mgr, rdr, gprof, dim, band, tc, device)
-            # image rows of this band: accumulator rows [r0, r1) less the frame's own gutter rows
-            y0, y1 = max(r0 - g, 0), min(r1 - g, dim.h)
-            if y1 > y0:
-                j0 = y0 + g - (r0 - top) - g                 # band output row of image row y0
-                _lib.check(lib.fl_ctx_sync(fb.ctx))
-                mine[y0 + g - r0:y1 + g - r0] = out[j0:j0 + (y1 - y0)]
+        out, bdim = filter_band(mgr, rdr, gprof, dim, band, tc, device)
+        # image rows of this band: accumulator rows [r0, r1) less the frame's own gutter rows
+        y0, y1 = max(r0 - g, 0), min(r1 - g, dim.h)
+        if y1 > y0:
+            j0 = y0 + g - (r0 - top) - g                 # band output row of image row y0
+            _lib.check(lib.fl_ctx_sync(fb.ctx))
+            mine[y0 + g - r0:y1 + g - r0] = out[j0:j0 + (y1 - y0)]
         allb = torch.empty((world * rows_per, dim.w, 4), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(allb, mine) if dist.get_backend() == 'nccl' else dist.all_gather(list(allb.view(world, rows_per, dim.w, 4).unbind(0)), mine)
         frame = allb[g:g + dim.h]
+        # asynchronous copy into the pinned frame buffer; the handle completes when the copy has (render.py:26-38)
         h_out = fb.host_buffer(rdr.out.shape(dim), rdr.out.dtype)
-        h_out[...] = frame.cpu().numpy().view(h_out.dtype)
-        _lib.check(lib.fl_ctx_sync(fb.ctx))
-        return DurationEvent(fb, fid.value), h_out
+        torch.from_numpy(h_out.view(np.uint8 if rdr.out.dtype == 'u1' else np.int16)).copy_(frame, non_blocking=True)
+        t_end = torch.cuda.Event(enable_timing=True)
+        t_end.record()
+        return TorchFrameEvent(t_start, t_end, keep=(allb, frame)), h_out
     if world > 1:
         acc = accumulator_tensor(fb, device, dim)      # waits for the iterate + flush kernels
         sum_accumulators(acc)

@@ -7,6 +7,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from common import REPO
 
 WORKER = textwrap.dedent('''
@@ -327,14 +329,19 @@ BAND_WORKER = textwrap.dedent('''
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
     from cuburn_amd import distributed as D
+    world = int(os.environ['WORLD'])
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['PORT'],
-                            rank=int(os.environ['RANK']), world_size=2)
-    rank, world = dist.get_rank(), 2
-    for ah in (1104, 480, 2192):
-        accs = [np.random.RandomState(100 * ah + r).rand(ah, 12).astype(np.float32) for r in range(world)]
-        total = accs[0] + accs[1]
+                            rank=int(os.environ['RANK']), world_size=world)
+    rank = dist.get_rank()
+    done = 0
+    for ah in (1104, 480, 2192, 4352):
         plan = D.band_plan(ah, world)
-        assert plan is not None
+        if plan is None:
+            continue
+        accs = [np.random.RandomState(100 * ah + r).rand(ah, 12).astype(np.float32) for r in range(world)]
+        total = accs[0].copy()
+        for a in accs[1:]:
+            total += a                                   # gloo sums in rank order as well
         rows_per, ranges = plan
         assert rows_per %% 16 == 0 and ranges[0][0] == 0 and ranges[-1][1] == ah
         band, top = D.exchange_bands(torch.from_numpy(accs[rank].copy()), plan, rank, world)
@@ -342,8 +349,9 @@ BAND_WORKER = textwrap.dedent('''
         assert top == (D.BAND_HALO if r0 > 0 else 0)
         want = total[r0 - top:min(r1 + D.BAND_HALO, ah)]
         assert band.shape == want.shape and band.shape[0] %% 16 == 0, (band.shape, want.shape)
-        assert np.array_equal(band.numpy(), want)
-    assert D.band_plan(400, 2) is None and D.band_plan(1104, 1) is None          # bands shorter than the halo; one rank
+        assert np.allclose(band.numpy(), want, rtol=1e-6, atol=0), ah
+        done += 1
+    assert done >= (2 if world <= 4 else 1), done
     if rank == 0:
         print('BANDS_OK')
     dist.barrier()
@@ -351,18 +359,91 @@ BAND_WORKER = textwrap.dedent('''
 ''') % REPO
 
 
-def test_row_band_exchange_world2(tmp_path):
-    """Sample-sharded frames are summed by row bands: every rank ends up with the sum of its own rows plus 224
-    halo rows from its neighbours (reduce-scatter + neighbour exchange on RCCL; the gloo stand-in all-reduces
-    and slices — same rows, same values)."""
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_row_band_exchange(tmp_path, world):
+    '''Sample-sharded frames are summed by row bands: every rank ends up with the sum of its own rows plus 224
+    halo rows from its neighbours.  RCCL: reduce-scatter; gloo has none and all-reduces, then keeps its own band —
+    the isend / irecv halo exchange that follows is the same code on both backends, and here it runs with a
+    middle rank (world 3) and with 4K on 8 ranks, whose last band (176 rows) is shorter than the halo.'''
     script = tmp_path / 'worker.py'
     script.write_text(BAND_WORKER)
-    port = str(29700 + os.getpid() % 200)
+    port = str(29700 + (os.getpid() + 7 * world) % 200)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), PORT=port, MASTER_ADDR='127.0.0.1')
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD=str(world), PORT=port, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=240)[0] for p in procs]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'BANDS_OK' in outs[0]
+
+
+def test_band_and_halo_plans_are_consistent():
+    '''The band plan + halo sizes + peer lists of the RCCL path as a pure function: for every accumulator height of
+    the BASELINE configs and 2..16 ranks, every send has a matching receive of the same size on the peer, the rows a
+    rank ends up with are exactly [r0 - 224, r1 + 224) clipped to the image, and no rank is left without rows.'''
+    from cuburn_amd import distributed as D
+    H = D.BAND_HALO
+    assert D.band_plan(400, 2) is None and D.band_plan(1104, 1) is None          # bands shorter than the halo; one rank
+    seen_short_last = False
+    for ah in (1104, 2192, 4352, 480, 8672):
+        for world in range(2, 17):
+            plan = D.band_plan(ah, world)
+            if plan is None:
+                rows_per = 16 * -(-ah // (16 * world))
+                assert rows_per < H or (world - 1) * rows_per >= ah
+                continue
+            rows_per, bands = plan
+            assert rows_per % 16 == 0 and rows_per >= H and len(bands) == world
+            assert bands[0][0] == 0 and bands[-1][1] == ah
+            assert all(b[1] > b[0] and b[0] % 16 == 0 for b in bands)            # no empty band
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            assert all(b[1] - b[0] == rows_per for b in bands[:-1])
+            hps = [D.halo_plan(plan, r, ah) for r in range(world)]
+            for r, hp in enumerate(hps):
+                r0, r1 = bands[r]
+                assert hp['top'] == (H if r > 0 else 0)
+                assert hp['bot'] == min(H, ah - r1)
+                assert (hp['top'] + (r1 - r0) + hp['bot']) % 16 == 0
+                for peer, first, rows in hp['sends']:
+                    assert abs(peer - r) == 1 and 0 <= first and first + rows <= r1 - r0 and rows > 0
+                    # the peer expects exactly these rows: my first rows as its bottom halo, my last rows as its top halo
+                    side = 'bot' if peer < r else 'top'
+                    match = [x for x in hps[peer]['recvs'] if x[0] == r and x[1] == side]
+                    assert len(match) == 1 and match[0][2] == rows, (ah, world, r, peer)
+                    # and they are the rows adjacent to the peer's band
+                    if side == 'bot':
+                        assert first == 0
+                    else:
+                        assert first + rows == r1 - r0
+                for peer, side, rows in hp['recvs']:
+                    assert [x for x in hps[peer]['sends'] if x[0] == r and x[2] == rows], (ah, world, r, peer)
+            if bands[-1][1] - bands[-1][0] < H:
+                seen_short_last = True
+    assert seen_short_last                                                       # e.g. 4K on 8 ranks: 176 rows
+    assert D.band_plan(2192, 8)[1][-1] == (2016, 2192)
+
+
+def test_chain_reach_covers_every_spatial_filter():
+    '''The band halo must cover the reach of the profile's chain: the DE, and the blurs of haloclip / smearclip.'''
+    from cuburn_amd import distributed as D, filters
+    assert set(D.FILTER_REACH) <= set(filters.Filter.filter_map)
+    assert D.chain_reach(['yuv', 'bilateral', 'logscale', 'colorclip']) == 192
+    assert D.chain_reach(['yuv', 'bilateral', 'haloclip', 'smearclip', 'logscale', 'colorclip']) == 207 <= D.BAND_HALO
+    assert D.chain_reach(['yuv', 'bilateral', 'bilateral']) > D.BAND_HALO        # such a profile takes the all-reduce path
+
+
+def test_band_path_only_for_interleaved_frames():
+    """Sample-sharded frames take the row-band path only when the output is an interleaved (h, w, 4) frame: the
+    encoders' planar YUV frames (3, h, w) cannot be cut into row bands of interleaved pixels and go through the
+    all-reduce path like every output did before the band path existed."""
+    from cuburn_amd import distributed as D, output, encoders
+    from cuburn_amd.render import Framebuffers
+    dim = Framebuffers.calc_dim(1920, 1080)
+    chain = ['yuv', 'bilateral', 'logscale', 'colorclip']
+    assert D.band_path_ok(output.Output(), dim, chain)
+    assert D.band_path_ok(output.TiffOutput(), dim, chain) and D.band_path_ok(output.Raw16Output(), dim, chain)
+    planar = [encoders.ProResOutput(), encoders.VPxOutput('vp9', pix_fmt='yuv420p'), encoders.VPxOutput('vp9', pix_fmt='yuv444p10')]
+    for out in planar:
+        assert len(out.shape(dim)) in (1, 3) and not D.band_path_ok(out, dim, chain), type(out).__name__
+    assert not D.band_path_ok(output.Output(), dim, ['yuv', 'bilateral', 'bilateral'])     # reach 384 > halo

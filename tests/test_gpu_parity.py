@@ -1016,19 +1016,23 @@ def test_sample_sharded_frame_two_virtual_ranks(built):
         m.fb.free()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_band_filtering_matches_whole_frame(built, world):
+@pytest.mark.parametrize('world,order', [(2, None), (4, None), (3, ['bilateral', 'logscale', 'haloclip', 'smearclip'])])
+def test_band_filtering_matches_whole_frame(built, world, order):
     """Sample-sharded frames filter by row bands (distributed.py): a band of summed accumulator rows plus 224 halo
     rows on either side is filtered as an image of its own, with the FULL frame's scalars.  On one GPU: cut the
     accumulator of a 1080p frame into the bands `world` ranks would own, filter each band, stitch the bands' own rows
     together, and compare with the chain run on the whole frame.  The filters are local and the halo exceeds the
     chain's reach (8 x 24 rows), so the interior is the same computation; tiles that touch a band's artificial edge
     take the nested form of the density blurs where the whole frame takes the regrouped 19-tap form (de.hip): 1e-7
-    relative in the blurred density, far below the bar."""
+    relative in the blurred density, far below the bar.  The third case adds the two other filters that look at
+    neighbouring rows (haloclip: two 7-tap blurs, smearclip: four; distributed.FILTER_REACH): the chain's reach is
+    then 207 of the 224 halo rows."""
     import torch
     from cuburn_amd import distributed as D
     gnm, prof = configs.cfg2()
     prof = dict(prof, spp=2 ** 26 / (1920.0 * 1080.0))
+    if order is not None:
+        prof = dict(prof, filter_order=order)
     gprof = profile.wrap(prof, gnm)
     m = render.RenderManager(device=0, host_seed=9)
     rdr = render.Renderer(gnm, gprof)
@@ -1049,6 +1053,7 @@ def test_band_filtering_matches_whole_frame(built, world):
     whole = m.fb.read('front', (dim.ah, dim.astride * 4), np.float32)
     assert whole.max() > 0.5
 
+    assert D.band_path_ok(rdr.out, dim, [f.name for f in rdr.filts])
     plan = D.band_plan(dim.ah, world)
     assert plan is not None and all(r0 % 16 == 0 and r1 % 16 == 0 for r0, r1 in plan[1])
     assert plan[1][0][0] == 0 and plan[1][-1][1] == dim.ah and all(a[1] == b[0] for a, b in zip(plan[1], plan[1][1:]))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction-mix / stall counters of the bench kernels, a few SQ counters per pass.
-# Usage: tools/pmc_sq.sh <tag> [kernel-substring]
+# Usage: [BENCH_ARGS="--config cfg5"] tools/pmc_sq.sh <tag> [kernel-substring]
 export TMPDIR=/tmp
 export FLAME_LANES=1
 tag=$1; kern=${2:-k_iter}
@@ -9,7 +9,7 @@ groups=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVES SQ_BU
         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC" "SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32")
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/sq_${tag}_$i -o b -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --preheat-seconds 0 --min-timed-frames 0 > gpurun_out/sq_${tag}_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/sq_${tag}_$i -o b -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --preheat-seconds 0 --min-timed-frames 0 $BENCH_ARGS > gpurun_out/sq_${tag}_$i.log 2>&1
   i=$((i+1))
 done
 python3 - <<PY

@@ -1,0 +1,81 @@
+// vgpr_bank_bench.hip — what a wave-instruction of the vector ALU costs a SIMD of gfx950 when its source operands
+// come from distinct registers (as in real code) instead of the two shared ones of tools/valu_bench.hip:
+// 16 independent v_fma_f32 per loop iteration with explicitly numbered registers, sources in three different
+// register banks (index mod 4), in one bank, or two of them the same register; wall-clock ns per wave-instruction
+// per SIMD with 8 waves per SIMD (256-thread workgroups, 8 per CU).
+//   hipcc --offload-arch=gfx950 -O2 -o tools/vgpr_bank_bench tools/vgpr_bank_bench.hip && tools/vgpr_bank_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define LOOPS 2048
+#define CLOB "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47", \
+             "v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63"
+// D = dst, sources A B C
+#define F(D, A, B, C) "v_fma_f32 v" #D ", v" #A ", v" #B ", v" #C "\n\t"
+template <int OP>
+__global__ void __launch_bounds__(256) k(float *out, float seed)
+{
+    asm volatile("v_mov_b32 v32, %0\n\tv_mov_b32 v33, %0\n\tv_mov_b32 v34, %0\n\tv_mov_b32 v35, %0\n\t"
+                 "v_mov_b32 v36, %0\n\tv_mov_b32 v37, %0\n\tv_mov_b32 v38, %0\n\tv_mov_b32 v39, %0\n\t"
+                 "v_mov_b32 v40, %0\n\tv_mov_b32 v41, %0\n\tv_mov_b32 v42, %0\n\tv_mov_b32 v43, %0\n\t"
+                 "v_mov_b32 v44, %0\n\tv_mov_b32 v45, %0\n\tv_mov_b32 v46, %0\n\tv_mov_b32 v47, %0\n\t"
+                 "v_mov_b32 v48, %0\n\tv_mov_b32 v49, %0\n\tv_mov_b32 v50, %0\n\tv_mov_b32 v51, %0\n\t"
+                 "v_mov_b32 v52, %0\n\tv_mov_b32 v53, %0\n\tv_mov_b32 v54, %0\n\tv_mov_b32 v55, %0\n\t"
+                 "v_mov_b32 v56, %0\n\tv_mov_b32 v57, %0\n\tv_mov_b32 v58, %0\n\tv_mov_b32 v59, %0\n\t"
+                 "v_mov_b32 v60, %0\n\tv_mov_b32 v61, %0\n\tv_mov_b32 v62, %0\n\tv_mov_b32 v63, %0" :: "v"(seed) : CLOB);
+    for (int it = 0; it < LOOPS; ++it) {
+        if (OP == 0)        // sources in three different banks (dst = the bank left over): v(4k+1), v(4k+2), v(4k+3) -> v(4k)
+            asm volatile(F(32,49,50,51) F(36,53,54,55) F(40,57,58,59) F(44,61,62,63) F(33,50,51,48) F(37,54,55,52) F(41,58,59,56) F(45,62,63,60)
+                         F(34,51,48,49) F(38,55,52,53) F(42,59,56,57) F(46,63,60,61) F(35,48,49,50) F(39,52,53,54) F(43,56,57,58) F(47,60,61,62) ::: CLOB);
+        else if (OP == 1)   // all three sources in ONE bank
+            asm volatile(F(32,48,52,56) F(36,49,53,57) F(40,50,54,58) F(44,51,55,59) F(33,52,56,60) F(37,53,57,61) F(41,54,58,62) F(45,55,59,63)
+                         F(34,48,56,60) F(38,49,57,61) F(42,50,58,62) F(46,51,59,63) F(35,48,52,60) F(39,49,53,61) F(43,50,54,62) F(47,51,55,63) ::: CLOB);
+        else if (OP == 2)   // two sources in one bank, the third elsewhere
+            asm volatile(F(32,48,52,57) F(36,49,53,58) F(40,50,54,59) F(44,51,55,56) F(33,52,56,61) F(37,53,57,62) F(41,54,58,63) F(45,55,59,60)
+                         F(34,48,56,61) F(38,49,57,62) F(42,50,58,63) F(46,51,59,60) F(35,48,52,61) F(39,49,53,62) F(43,50,54,63) F(47,51,55,60) ::: CLOB);
+        else if (OP == 3)   // accumulate form: dst is also the addend (v_fmac), other two sources in different banks
+            asm volatile(F(32,49,50,32) F(36,53,54,36) F(40,57,58,40) F(44,61,62,44) F(33,50,51,33) F(37,54,55,37) F(41,58,59,41) F(45,62,63,45)
+                         F(34,51,48,34) F(38,55,52,38) F(42,59,56,42) F(46,63,60,46) F(35,48,49,35) F(39,52,53,39) F(43,56,57,43) F(47,60,61,47) ::: CLOB);
+        else if (OP == 4)   // one SGPR-free two-operand op: v_add_f32, sources in different banks
+            asm volatile("v_add_f32 v32, v49, v50\n\tv_add_f32 v36, v53, v54\n\tv_add_f32 v40, v57, v58\n\tv_add_f32 v44, v61, v62\n\t"
+                         "v_add_f32 v33, v50, v51\n\tv_add_f32 v37, v54, v55\n\tv_add_f32 v41, v58, v59\n\tv_add_f32 v45, v62, v63\n\t"
+                         "v_add_f32 v34, v51, v48\n\tv_add_f32 v38, v55, v52\n\tv_add_f32 v42, v59, v56\n\tv_add_f32 v46, v63, v60\n\t"
+                         "v_add_f32 v35, v48, v49\n\tv_add_f32 v39, v52, v53\n\tv_add_f32 v43, v56, v57\n\tv_add_f32 v47, v60, v61" ::: CLOB);
+        else if (OP == 5)   // v_pk_fma_f32, register pairs, sources in different bank pairs
+            asm volatile("v_pk_fma_f32 v[32:33], v[48:49], v[50:51], v[52:53]\n\tv_pk_fma_f32 v[34:35], v[54:55], v[56:57], v[58:59]\n\t"
+                         "v_pk_fma_f32 v[36:37], v[60:61], v[62:63], v[48:49]\n\tv_pk_fma_f32 v[38:39], v[50:51], v[52:53], v[54:55]\n\t"
+                         "v_pk_fma_f32 v[40:41], v[56:57], v[58:59], v[60:61]\n\tv_pk_fma_f32 v[42:43], v[62:63], v[48:49], v[50:51]\n\t"
+                         "v_pk_fma_f32 v[44:45], v[52:53], v[54:55], v[56:57]\n\tv_pk_fma_f32 v[46:47], v[58:59], v[60:61], v[62:63]\n\t"
+                         "v_pk_fma_f32 v[32:33], v[48:49], v[50:51], v[52:53]\n\tv_pk_fma_f32 v[34:35], v[54:55], v[56:57], v[58:59]\n\t"
+                         "v_pk_fma_f32 v[36:37], v[60:61], v[62:63], v[48:49]\n\tv_pk_fma_f32 v[38:39], v[50:51], v[52:53], v[54:55]\n\t"
+                         "v_pk_fma_f32 v[40:41], v[56:57], v[58:59], v[60:61]\n\tv_pk_fma_f32 v[42:43], v[62:63], v[48:49], v[50:51]\n\t"
+                         "v_pk_fma_f32 v[44:45], v[52:53], v[54:55], v[56:57]\n\tv_pk_fma_f32 v[46:47], v[58:59], v[60:61], v[62:63]" ::: CLOB);
+    }
+    float s;
+    asm volatile("v_add_f32 %0, v32, v47" : "=v"(s) :: CLOB);
+    if (s == 1.2345e-33f) out[0] = s;
+}
+template <int OP> static void run(const char *name, float *d, int ncu)
+{
+    const int wps = 8, blocks = ncu * wps;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+    hipEventRecord(e1, 0); hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-64s %6.3f ns per wave-instruction per SIMD (8 waves per SIMD)\n", name, ms / 5 * 1e6 / (LOOPS * 16.0 * wps));
+}
+int main()
+{
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    printf("device %s, %d CUs, clock %d kHz: 4 clocks = %.3f ns\n", p.gcnArchName, p.multiProcessorCount, p.clockRate, 4e6 / p.clockRate);
+    float *d; hipMalloc(&d, 64);
+    run<0>("v_fma_f32, three sources in three banks", d, p.multiProcessorCount);
+    run<2>("v_fma_f32, two sources in one bank", d, p.multiProcessorCount);
+    run<1>("v_fma_f32, three sources in one bank", d, p.multiProcessorCount);
+    run<3>("v_fma_f32 accumulating (dst = addend), sources in two banks", d, p.multiProcessorCount);
+    run<4>("v_add_f32, two sources in two banks", d, p.multiProcessorCount);
+    run<5>("v_pk_fma_f32, register pairs", d, p.multiProcessorCount);
+    return 0;
+}
