@@ -48,6 +48,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0    # MI355X_MICROARCH.md, HBM: ~6.3 TB/s achievable
 
 
 def usable_cores():
@@ -354,7 +355,9 @@ def main():
         traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
         try:        # measured offline with tools/pmc_traffic.sh on this workload (KB units, reads x2)
             import glob
-            pmc_file = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r0*_pmc_traffic.json')))[-1]
+            # profiles/rNN_pmc_traffic.json is cfg2's; the other configs' files carry the config in their name
+            pat = 'r0*_pmc_traffic.json' if args.config == 'cfg2' else 'r0*_%s_pmc_traffic.json' % args.config
+            pmc_file = sorted(glob.glob(os.path.join(REPO, 'profiles', pat)))[-1]
             pmc = json.load(open(pmc_file))
             def kb(sub):
                 tot = 0.0
@@ -363,13 +366,16 @@ def main():
                         c = pmc[k]
                         tot += (2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024
                 return tot
-            if args.config == 'cfg2' and args.accum == 'binned':
+            if args.accum == 'binned':
+                # per LAUNCH in the file; a frame of more than 2^28 samples has several iterate / accumulate / flush launches
+                nl = max(acc['launches'], 1) / float(ksteps)
                 iter_bytes = int(kb('k_iter'))
-                traffic = int(iter_bytes + kb('k_accum_tiles') + kb('k_flush'))
+                traffic = int((iter_bytes + kb('k_accum_tiles') + kb('k_flush')) * nl)
                 de_traffic = int(kb('k_de_')) or None
         except Exception:
-            traffic, iter_bytes, de_traffic = None, None, None
+            traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
         launches = max(acc['launches'], 1)
+        big_ms = (acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps
         iter_launch_s = acc['iter_ms'] * 1e-3 / launches
         de_s = (acc['de_ms'] + acc['de_finish_ms']) * 1e-3 / ksteps
         de_gbs = 512.0 * nbins / de_s / 1e9 if de_s > 0 else 0.0            # 64 B/px/direction x 8
@@ -386,11 +392,16 @@ def main():
                        else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
                             % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
                        'walker_waves': mgr.fb.nw, 'walker_slots': mgr.fb.nslots,
-                       'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step, 'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round((acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps, 4),
-                                        'note': 'the big kernels do not overlap usefully (DESIGN 4.1): the second lane hides copies, clears and launch gaps only'},
+                       'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step,
+                       'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round(big_ms, 4),
+                                        'overlap_ms_per_frame': round(big_ms - elapsed / args.steps * 1e3, 4),
+                                        'note': 'sum_of_big_kernels_ms = iterate + accumulate + flush + filter kernels of a frame timed alone on one lane; '
+                                                'overlap_ms_per_frame = that sum minus ms_per_step: what the second lane hides (kernels of frame k+1 '
+                                                'running in the issue slots and on the CUs that frame k leaves idle, plus copies, clears and launch gaps)'},
                        'accum': args.accum, 'preheat_s': args.preheat_seconds, 'fuse': fuse_main, 'nslots': mgr.fb.nslots,
                        'frames_queued_ahead': args.depth, 'frames_per_gpu': args.steps,
-                       'per_genome_kernel': os.environ.get('FLAME_RTC', '1') != '0',
+                       'per_genome_kernel': {'iterate_launches': int(acc['spec_launches']), 'interpreter_launches': int(acc['interp_launches']),
+                                             'note': 'counted by the library (fl_launch_stats) over the kernel-timing frames'},
                        'fuse_short': {'fuse': fuse_other, 'value': round(job_samples_per_step * args.steps / elapsed_ref / 1e6, 2),
                                       'ms_per_step': round(elapsed_ref / args.steps * 1e3, 3),
                                       'iter_chain_ms_per_frame': round(chain_ref_s / ksteps * 1e3, 4),
@@ -402,6 +413,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter + k_accum_tiles + k_flush (iterate chain: the 8-byte packed-cell RMW per sample)',
                          'achieved': round(chain, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(chain / HBM_PEAK_GBS, 5),
                          'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file else None,
+                         'traffic_measured_in_this_run': False,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
                          'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'vector / scalar issue and the per-round barrier (65 % of the wall-clock VALU peak; not bandwidth)',
@@ -417,6 +429,7 @@ def main():
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
+                          'frac_of_achievable_6300': round(de_gbs / HBM_ACHIEVABLE_GBS, 5),
                           'traffic': de_traffic,
                           'bound': 'workgroup phase latency x vector ALU (DESIGN 4.3: 55-65 % of the wall-clock VALU peak, 15 % of HBM): 512 B/px is the algorithmic byte count of the reference pass structure'},
             'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),

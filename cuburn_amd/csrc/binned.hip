@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024, TWL == 7u ? 8 
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
-              uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap)
+              uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap, uint32_t big_thr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
@@ -438,8 +438,10 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 if (v != 0ull && px < astride && py < aheight) {
                     // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
                     // most `nparts` adds per launch (one per workgroup of its tile) onto a flushed cell,
-                    // so chunks below 1024/nparts hits are safe; larger ones go straight to the floats.
-                    if ((uint32_t)(v >> 54) >= 1024u / nparts) big |= 1u << k;
+                    // so chunks below big_thr = 1024/nparts hits are safe; larger ones go straight to the floats.
+                    // (When the flush waits for the frame's last launch a cell may start a launch with up to
+                    // 255 + big_thr - 1 hits — whoever finds 256 or more drains it —: big_thr = 768 / (nparts + 1).)
+                    if ((uint32_t)(v >> 54) >= big_thr) big |= 1u << k;
                     else                                         // (as asm: the compiler waits for every returning atomic at the end of its branch)
                         asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "+v"(old[k]) : "v"(atom + py * astride + px), "v"(v) : "memory");
                 }
@@ -474,8 +476,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
                         u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
-                        uint32_t astride, uint32_t aheight, bool wide)
+                        uint32_t astride, uint32_t aheight, bool wide, bool flushed)
 {
+    const uint32_t big_thr = flushed ? 1024u / nparts : 768u / (nparts + 1u);
     // LDS: the tile, 64 marks per wave, and as many palette rows (2 KB each) as the slot range of one
     // workgroup touches — capped by what lets two narrow workgroups (one wide) share a CU's 160 KB
     const uint32_t spr = nslots / FL_PAL_H, slots_per_part = (nslots + nparts - 1) / nparts;
@@ -487,12 +490,12 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
         ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, attr);
         hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024),
                            (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4 + rows * FL_PAL_W * 8, st,
-                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows);
+                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr);
         return;
     }
     const uint32_t rows = want < 2u ? 2u : want > (uint32_t)ACC_ROWS_MAX ? (uint32_t)ACC_ROWS_MAX : want;
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
     hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
-                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows);
+                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr);
 }

@@ -47,6 +47,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 struct DeCoefs { float k[7]; float k2[19]; };      // the blur's 7 taps; both blurs as ONE 19-tap kernel (integer-step directions)
 struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
@@ -753,6 +754,43 @@ __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__rest
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
 }
 
+// Workgroups per CU.  A direction's tiles all cost the same and a CU holds R workgroups at a time, so the kernel takes
+// ceil(tiles per CU / R) rounds of one workgroup lifetime each — and the lifetime itself is R waves per SIMD sharing one
+// vector ALU, i.e. proportional to R: time ~ ceil(T / R) * R.  With R = 8 a 1080p direction of 8540 tiles (33.4 per
+// CU) runs 5 rounds for 4.17 rounds' worth of work; with R = 7 the same 5 rounds are 12 % shorter.  R is enforced through
+// the dynamic-LDS request (more LDS than the kernel uses); the choice minimises ceil(T / R) * R over the R the
+// kernel's registers and LDS allow, preferring the larger R on ties (latency hiding).  FLAME_DE_WGS="r0,r1,..,r7"
+// overrides per direction (0 = the kernel's maximum).
+static size_t de_lds_for_residency(size_t lds, int nt, uint32_t ntiles, int pattern)
+{
+    const int ncu = 256, lds_cu = 160 * 1024;
+    const int rmax = std::min<int>(2048 / nt, (int)(lds_cu / lds));
+    int want = 0;
+    static int forced[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    if (forced[0] == -1) {
+        for (int i = 0; i < 8; ++i) forced[i] = -2;
+        if (const char *e = getenv("FLAME_DE_WGS")) {
+            int i = 0;
+            for (const char *q = e; *q && i < 8; ++i) { forced[i] = atoi(q); q = strchr(q, ','); if (!q) break; ++q; }
+        }
+    }
+    if (forced[pattern] >= 0) want = forced[pattern];
+    else {
+        const double t = (double)ntiles / ncu;
+        double best = 1e30;
+        for (int r = rmax; r >= std::max(2, rmax - 2); --r) {       // (fewer than rmax - 2 costs more latency hiding than rounding wins)
+            const double cost = std::ceil(t / r) * r;
+            if (cost < best - 1e-9) { best = cost; want = r; }
+        }
+    }
+    if (want <= 0 || want >= rmax) return lds;
+    // the smallest request that no longer fits `want + 1` times: LDS is handed out in 1 KB steps... use half-way
+    const size_t per = (size_t)lds_cu / want;                       // fits `want` times
+    const size_t floor_next = (size_t)lds_cu / (want + 1) + 1024;   // does not fit `want + 1` times
+    size_t req = std::max(lds, std::min(per, std::max(floor_next, (per + (size_t)lds_cu / (want + 1)) / 2)));
+    return req & ~(size_t)255;
+}
+
 template <int P, int IN, int OUT>
 static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const float4 *N, DeCoefs kc, DeSpatial spk,
                               float cs2, float ads, float dpow, float gspeed, DeTail tail)
@@ -763,7 +801,7 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
     ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(G::NT), G::LDS, st, d, Nout, N, kc, spk,
+    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(G::NT), de_lds_for_residency(G::LDS, G::NT, ntiles, P), st, d, Nout, N, kc, spk,
                        cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
 }
 

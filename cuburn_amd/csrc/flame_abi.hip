@@ -83,6 +83,8 @@ struct fl_ctx {
     u64 *d_counters = nullptr;
     uint32_t *d_sort = nullptr; size_t sort_words = 0;     // radix sort scratch (grow-only): digit counts + chunk totals
     uint32_t bin_rounds = 16, bin_parts = 0;      // bin_parts 0: chosen per image (see do_iter_launch)
+    uint32_t launch_rounds = 0;                   // FLAME_LAUNCH_ROUNDS: write-enabled rounds per binned launch (0: FL_BIN_MAX_ROUNDS) — the sample log of a launch is nslots x 256 x rounds x 4 bytes
+    bool env_flush_last = false;                  // FLAME_FLUSH_LAST=1: one k_flush at the end of the frame instead of one per launch
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
@@ -94,6 +96,7 @@ struct fl_ctx {
     // environment switches, read once when the context is created
     bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
+    uint32_t n_spec_launch = 0, n_interp_launch = 0;      // iterate launches by kernel since fl_timings_reset (fl_launch_stats)
 };
 #define L(c) ((c)->lanes[(c)->cur])
 #define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
@@ -245,6 +248,8 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
+    if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
+    c->env_flush_last = env_on("FLAME_FLUSH_LAST");
     c->env_de_unfused_ends = env_on("FLAME_DE_UNFUSED_ENDS");   // separate normalise / un-normalise passes around the 8 directions
     c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
@@ -611,6 +616,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         }
         fn = slot;
     }
+    (fn ? c->n_spec_launch : c->n_interp_launch) += 1;
     if (fn)
         launch_iter_fn(L(c).stream, fn, c->nw, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                        L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
@@ -636,7 +642,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         uint32_t parts = c->bin_parts ? c->bin_parts : (wide ? 16384u : 8192u) / nbins;
         parts = parts < 1u ? 1u : parts > (c->bin_parts ? 64u : 16u) ? (c->bin_parts ? 64u : 16u) : parts;
         launch_accum_tiles(drain, L(c).d_log[buf], L(c).d_dir[buf], L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
-                           parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
+                           parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide, !c->env_flush_last);
         ev_end_on(e2, drain);
         HIPCHK(hipGetLastError());
     }
@@ -678,7 +684,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     // + flush of each launch go to the lane's aux stream, with two log / directory sets: launch k+1
     // iterates while launch k drains.  (Both kernels want the whole chip, so this buys little —
     // DESIGN.md §4.1 — but it costs nothing and hides the drains' launch gaps.)
-    const uint64_t cap = accum_mode == FL_ACCUM_BINNED ? FL_BIN_MAX_ROUNDS : ~0ull;
+    const uint64_t cap = accum_mode == FL_ACCUM_BINNED ? (c->launch_rounds ? c->launch_rounds : FL_BIN_MAX_ROUNDS) : ~0ull;
     uint32_t nlaunch = 0;
     for (uint64_t r = rounds, b = 4; r; b += b / 2) { uint64_t n = std::min(std::min(r, b * 256), cap); r -= n; ++nlaunch; }
     const bool pipelined = accum_mode == FL_ACCUM_BINNED && nlaunch > 1 && !c->env_no_intra;
@@ -692,7 +698,10 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
         // the drains of launch k-2 read this log / directory set: they must be done before it is rewritten
         if (pipelined && k >= 2) HIPCHK(hipStreamWaitEvent(L(c).stream, L(c).ev_ac[buf], 0));
         if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false, accum_mode, buf, drain))) return rc;
-        if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED, drain))) return rc;
+        // (binned mode: the packed cells take the next launch's tile adds on top of this one's — a cell is drained by the
+        // add that finds it at 256 hits — so the flush may wait for the frame's last launch: FLAME_FLUSH_LAST)
+        if (!(c->env_flush_last && accum_mode == FL_ACCUM_BINNED && rounds > n))
+            if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED, drain))) return rc;
         if (pipelined) HIPCHK(hipEventRecord(L(c).ev_ac[buf], drain));
         rounds -= n;
         batch += batch / 2;
@@ -985,6 +994,7 @@ int fl_timings_reset(fl_ctx *c)
     REQUIRE(c, "null ctx");
     sync_all(c);
     c->iter_ev.clear(); c->accum_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->de_ev.clear(); c->definish_ev.clear(); c->pool_used = 0;
+    c->n_spec_launch = c->n_interp_launch = 0;
     return FL_OK;
 }
 
@@ -994,6 +1004,13 @@ int fl_timings_detail(fl_ctx *c, float ms[6])
     sync_all(c);
     ms[0] = sum_ms(c->iter_ev); ms[1] = sum_ms(c->accum_ev); ms[2] = sum_ms(c->flush_ev);
     ms[3] = sum_ms(c->filt_ev); ms[4] = sum_ms(c->de_ev); ms[5] = sum_ms(c->definish_ev);
+    return FL_OK;
+}
+
+int fl_launch_stats(fl_ctx *c, uint32_t out[4])
+{
+    REQUIRE(c && out, "null argument");
+    out[0] = c->n_spec_launch; out[1] = c->n_interp_launch; out[2] = c->nslots; out[3] = (uint32_t)c->nw;
     return FL_OK;
 }
 

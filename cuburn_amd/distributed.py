@@ -429,7 +429,7 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=
     if device is None:
         device = torch.cuda.current_device()
     fb = mgr.fb
-    dim = fb.set_dim(gprof.width, gprof.height)
+    dim = fb.set_dim(gprof.width, gprof.height, nsamples=sample_share(gprof.spp(tc) * gprof.width * gprof.height, rank, world))
     td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
     ts = tc - 0.5 * td
     g = rdr._handle(fb)

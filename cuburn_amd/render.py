@@ -97,7 +97,7 @@ class Framebuffers(object):
     # with up to 2^28 samples (one launch of <= 1024 rounds) the pipelined frame loop is 2.4-3.6 % faster (cfg2 1.44 ->
     # 1.39 ms) although the iterate kernel ALONE is 12 % slower at four instead of six waves per SIMD — the other
     # stream lane's kernels run beside it.  With more samples the second launch costs more than the fuse saves
-    # (profiles/r03_slots_by_samples.txt).  Decided when a context is first used for an image class, then kept.
+    # (profiles/r03_slots_by_samples.txt).  Decided per frame from its sample count (set_dim).
     NARROW_FEW = (4, 1024)
     FEW_SAMPLES = 2 ** 28
     WIDE_FROM_TILES = 1024
@@ -109,7 +109,6 @@ class Framebuffers(object):
         env_nw = os.environ.get('FLAME_NW')
         self._auto = nslots is None and env_nw is None
         self._cfg = (int(env_nw) if env_nw in ('8', '16') else 4, nslots if nslots is not None else self.NARROW[1])
-        self._narrow = None                 # the small-image geometry in use once a frame's sample count has been seen
         self._ctx = None
         self.generation = 0                 # bumped whenever the native context is re-created
         self.nout = 65536                   # RNG states of the output dither kernel
@@ -159,11 +158,14 @@ class Framebuffers(object):
             ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
             want = self.HUGE if ntiles > self.HUGE_FROM_TILES else self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
             if want == self.NARROW:
-                if self._narrow is None and nsamples is not None:       # first frame of this class: few samples -> fewer walkers
-                    self._narrow = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
-                want = self._narrow or (self._cfg if self._cfg in (self.NARROW, self.NARROW_FEW) else self.NARROW)
-            else:
-                self._narrow = None
+                # decided per FRAME from its sample count, so that (seed, frame) renders the same whatever was rendered
+                # before it, on whichever rank (a context that last held the other geometry is re-created: 1024 <-> 1536
+                # slots only changes when a job's samples per frame cross 2^28); without a sample count the small-image
+                # geometry in use is kept
+                if nsamples is not None:
+                    want = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
+                elif self._cfg in (self.NARROW, self.NARROW_FEW):
+                    want = self._cfg
             if want != self._cfg:
                 self._drop_ctx()
                 self._cfg = want
@@ -334,5 +336,8 @@ class RenderManager(object):
         _lib.check(_lib.load().fl_timings(self.fb.ctx, C.byref(it), C.byref(fl), C.byref(ft), C.byref(n)))
         d = (C.c_float * 6)()
         _lib.check(_lib.load().fl_timings_detail(self.fb.ctx, C.byref(d)))
+        st = (C.c_uint32 * 4)()
+        _lib.check(_lib.load().fl_launch_stats(self.fb.ctx, C.byref(st)))
         return dict(iter_ms=it.value, flush_ms=fl.value, filter_ms=ft.value, launches=n.value,
-                    accum_ms=d[1], flush_only_ms=d[2], de_ms=d[4], de_finish_ms=d[5])
+                    accum_ms=d[1], flush_only_ms=d[2], de_ms=d[4], de_finish_ms=d[5],
+                    spec_launches=st[0], interp_launches=st[1])

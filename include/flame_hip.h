@@ -245,6 +245,10 @@ int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, u
  * [4] the DE proper (FL_FILT_BILATERAL: seven directions, the first normalising the accumulator), [5] the call that
  * un-normalised the DE result (the last direction, with logscale / colorclip riding along when they follow directly). */
 int fl_timings_detail(fl_ctx *ctx, float ms[6]);
+/* Which iterate kernel actually ran since the last fl_timings_reset: out[0] launches of the kernel compiled for the
+ * genome's structure (hipRTC; the counterpart of the module the reference compiles per genome, cuburn/render.py:232-236),
+ * out[1] launches of the precompiled interpreter kernel (the fallback); out[2] walker slots, out[3] waves per slot. */
+int fl_launch_stats(fl_ctx *ctx, uint32_t out[4]);
 
 /* ---- debug taps (tests only): read/write device state ---- */
 enum {

@@ -252,13 +252,61 @@ def test_asm_issued_loads_are_not_touched_in_flight(tmp_path):
         pytest.skip('no hipcc')
     src = os.path.join(REPO, 'cuburn_amd', 'csrc', 'binned.hip')
     asm = str(tmp_path / 'binned.s')
-    r = subprocess.run([hipcc, '-O3', '-std=c++20', '--offload-arch=gfx950', '-ffp-contract=off', '--cuda-device-only',
-                        '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+    # the Makefile runs the same checker on the assembly of the object it ships (same flags) and fails the build on a
+    # violation; here the default flags once more, for the resource numbers, and the checker's own self-test
+    mk = open(os.path.join(REPO, 'cuburn_amd', 'csrc', 'Makefile')).read()
+    assert 'check_asm_atomics.py $(BUILD)/binned.s' in mk
+    r = subprocess.run([hipcc, '-O3', '-std=c++20', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',
+                        '--cuda-device-only', '-S', src, '-o', asm, '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    chk = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'check_asm_atomics.py'), asm], capture_output=True, text=True)
+    checker = os.path.join(REPO, 'tools', 'check_asm_atomics.py')
+    chk = subprocess.run([sys.executable, checker, asm], capture_output=True, text=True, timeout=120)
     assert chk.returncode == 0, chk.stdout[-2000:]
     assert not chk.stdout.startswith('0 asm-issued'), chk.stdout
+    # self-test: an instruction at the top of the pipelined loop that touches the record set in flight ACROSS the
+    # back-edge must be reported (by the second pass over the loop body), one that touches the completed set must not
+    lines = open(asm).read().split('\n')
+    load = re.compile(r'\s*global_load_dword v(\d+), v(\d+), s\[(\d+):(\d+)\]$')
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
+    loads = [(i, int(load.match(l).group(1))) for i, l in enumerate(lines) if load.match(l)]
+    head = back = None
+    for i in range(loads[0][0], len(lines)):
+        t = lines[i].strip().split()
+        if t and t[0].startswith('s_cbranch') and t[1] in labels and labels[t[1]] < loads[0][0]:
+            head, back = labels[t[1]], i
+            break
+    assert head is not None
+    flagged = 0
+    for reg in sorted(set(r for i, r in loads if head < i < back)):
+        inj = str(tmp_path / 'inj.s')
+        open(inj, 'w').write('\n'.join(lines[:head + 1] + ['\tv_mov_b32_e32 v0, v%d' % reg] + lines[head + 1:]))
+        out = subprocess.run([sys.executable, checker, inj], capture_output=True, text=True, timeout=120)
+        flagged += out.returncode != 0 and 'second pass' in out.stdout
+    assert 2 <= flagged <= 4, flagged                      # one of the two record sets (2-4 registers) is in flight there
     # resource usage of the narrow kernel, from the compiler's remarks
     rem = r.stderr[r.stderr.index('k_accum_tilesILj7'):]
     num = lambda key: int(re.search(key + r': (\d+)', rem).group(1))
     assert num('VGPRs') <= 64 and num('TotalSGPRs') <= 80 and num(r'ScratchSize \[bytes/lane\]') == 0, rem[:1200]
+
+
+def test_de_kernels_hold_32_waves_per_cu_without_scratch(tmp_path):
+    """Every k_de_dir kernel carries two forms of its 31-tap loop (waves whose centres are all live / waves with a dead
+    centre) and must still fit 64 vector registers — eight waves per SIMD — with no scratch: a private segment costs
+    every wave its set-up whether it spills on its path or not (de.hip: each form finds its pixel itself, the rare form
+    is not software-pipelined)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(REPO, 'cuburn_amd', 'csrc', 'de.hip')
+    r = subprocess.run([hipcc, '-O3', '-std=c++20', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',
+                        '-fgpu-flush-denormals-to-zero', '-fno-slp-vectorize', '--cuda-device-only', '-S', src, '-o', str(tmp_path / 'de.s'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels = re.split(r'Function Name: ', r.stderr)[1:]
+    de = [k for k in kernels if k.startswith('_Z8k_de_dir')]
+    assert len(de) == 11                                   # 8 directions, 3 input forms of the first, 2 output forms of the last
+    for k in de:
+        num = lambda key: int(re.search(key + r': (\d+)', k).group(1))
+        assert num('VGPRs') <= 64 and num(r'ScratchSize \[bytes/lane\]') == 0 and num('TotalSGPRs') <= 80, k[:300]

@@ -278,7 +278,8 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 def test_walker_geometry_follows_image_size():
     """A manager built without an explicit slot count uses 4-wave slots for small images — 1024 of
-    them for frames of up to 2^28 samples, 1536 above, decided by the first frame of the class —
+    them for frames of up to 2^28 samples, 1536 above, decided per frame from its sample count (the same
+    (seed, frame) renders the same whatever the context rendered before) —
     1024 x 8-wave slots from ~1440p up and 1024 x 16-wave slots above 4K (the native context is
     re-created on the switch, genome handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)
@@ -291,7 +292,7 @@ def test_walker_geometry_follows_image_size():
     evt, a = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()
     assert (m.fb.nw, m.fb.nslots) == (4, 1024) and m.fb.generation == gen0 + 1 and np.array(a)[..., 3].max() > 0
     gen0 += 1
-    evt, a1 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # decided once: no further switch
+    evt, a1 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # same class of frame: no further switch
     assert m.fb.generation == gen0
     evt, b = m.queue_frame(rdr_b, gnm, big, 0.5); evt.synchronize()
     assert (m.fb.nw, m.fb.nslots) == (16, 1024) and m.fb.generation == gen0 + 1
@@ -310,8 +311,11 @@ def test_walker_geometry_follows_image_size():
     many = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
     evt, _ = q.queue_frame(render.Renderer(gnm, many), gnm, many, 0.5); evt.synchronize()
     assert (q.fb.nw, q.fb.nslots) == (4, 1536) and q.fb.generation == 0
-    evt, _ = q.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()          # (and is kept for later frames of the class)
-    assert (q.fb.nw, q.fb.nslots) == (4, 1536) and q.fb.generation == 0
+    # ... and a frame of few samples after it gets the geometry it would have got as a first frame: the same pixels
+    # as manager m's first frame (same host seed, same frame), whatever this context rendered before
+    evt, a3 = q.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()
+    assert (q.fb.nw, q.fb.nslots) == (4, 1024) and q.fb.generation == 1
+    assert np.array_equal(np.array(a3), a.astype(np.uint8))
     q.fb.free()
     # an explicit slot count pins the geometry
     p = render.RenderManager(device=0, nslots=NSLOTS, host_seed=5)

@@ -1139,8 +1139,10 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     gprof = profile.wrap(prof, gnm)
     m = render.RenderManager(device=0, host_seed=42)              # production defaults
     rdr = render.Renderer(gnm, gprof)
-    dim = m.fb.calc_dim(gprof.width, gprof.height)
-    assert (dim.w, dim.h) == (1920, 1080)
+    # the geometry queue_frame picks for this frame (1024 slots of 4 waves for up to 2^28 samples): what bench.py's
+    # headline line runs
+    dim = m.fb.set_dim(gprof.width, gprof.height, nsamples=gprof.spp(0.5) * gprof.width * gprof.height)
+    assert (dim.w, dim.h) == (1920, 1080) and (m.fb.nw, m.fb.nslots) == (4, 1024)
     nbins = dim.ah * dim.astride
     tc = 0.5
     ts, td = frame_times(gprof, tc)
@@ -1162,7 +1164,7 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     assert np.array_equal(da, np.rint(da)) and da.min() >= 0            # integer counts
     assert da.sum() <= runs[0] and db.sum() <= runs[1]
     assert not np.array_equal(da, db)
-    F = prepare(gnm, prof, tc)
+    F = prepare(gnm, prof, tc, nslots=m.fb.nslots)
     ref, secs, acc = O.flam3_render(F['dim'], F['packer'].prog, F['params'], F['palette'], F['seeds'], 2 ** 28, 16)
     dr = density(ref, dim)
     assert abs(da.sum() / runs[0] - dr.sum() / 2 ** 28) < 2e-3, (da.sum() / runs[0], dr.sum() / 2 ** 28)
@@ -1196,6 +1198,15 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     # tone-mapped values live in [0, 1]: 8 DE passes + log + gamma in fast math on both sides
     from test_gpu_fullsize import check_chain_error
     check_chain_error(np.abs(dev - cur), 'cfg2 whole frame')
+    # queue_frame renders the same frame in the same context (no geometry switch), and its 8-bit frame is the chain's
+    # output: alpha > 0 exactly where the tone-mapped density is visible
+    gen = m.fb.generation
+    evt, h_out = m.queue_frame(rdr, gnm, gprof, tc)
+    evt.synchronize()
+    assert m.fb.generation == gen and (m.fb.nw, m.fb.nslots) == (4, 1024)
+    frame = np.array(h_out)
+    vis = dev.reshape(dim.ah, dim.astride, 4)[12:12 + dim.h, 12:12 + dim.w, 3] > 0.5 / 255
+    assert frame.shape == (1080, 1920, 4) and abs((frame[..., 3] > 0).mean() - vis.mean()) < 0.01
     m.fb.free()
 
 

@@ -159,7 +159,12 @@ def test_random_genome_parity(mgr, mgr_prod, seed):
             return a[:, 3].reshape(dim.ah, dim.astride)[:H, :W].reshape(H // 16, 16, W // 16, 16).sum((1, 3))
         bg, br = blocks(front), blocks(refh)
         l1 = np.abs(bg / bg.sum() - br / br.sum()).sum()
-        assert l1 < 0.05, l1
+        # the bar is the shot-noise floor of the two samples, sum over blocks of sqrt(2 / pi * p * (1/Ng + 1/Nr)), times 3
+        # (wave-coherent xform choice and the CPU game's eight long trajectories are both clustered samples: block z-scores
+        # of 1.0-1.2 against an independent game) plus 2 % — as tests/test_gpu_fullsize.py; round 3: 5 % flat
+        p = br / br.sum()
+        floor = np.sqrt(2 / np.pi * p * (1.0 / bg.sum() + 1.0 / br.sum())).sum()
+        assert l1 < 0.02 + 3 * floor, (l1, floor)
 
 
 def _blocks16(a, dim):

@@ -4,9 +4,14 @@ non-trivial pre and post affine) to 4096 points, HIP kernel vs oracle, through t
 
 Tolerance: the device uses single hardware instructions for sin/cos/exp/log/rcp/sqrt (as the
 reference does under -use_fast_math, cuburn/code/util.py:96), so results agree to ~1e-4
-relative for smooth variations; variations with floor/trunc/compare branches can flip a branch
-on a 1-ulp input difference, so the bar is: >= 99 % of points within 2e-3 relative / 2e-4
-absolute, RNG streams advance identically (bit-exact), colour exact.
+relative for smooth variations: every point must lie within 2e-3 relative / 2e-4 absolute of the
+oracle's, RNG streams advance identically (bit-exact), colour exact.  Variations with floor / trunc /
+compare branches can flip a branch on a 1-ulp difference of an intermediate, and a few are ill-conditioned
+in places (sin(tan(3y)) next to a pole of tan); a point outside the tolerance is accepted ONLY if the
+device's result is no further from the oracle's than the oracle's own results spread over the inputs
+within 6 ulp of the point (a discontinuity, or a condition number that makes 1 ulp of input worth more than the tolerance),
+and at most 1.5 % of the points may need that — anything else fails (round 3 accepted any 1 % of points
+unexamined).
 """
 import ctypes as C
 
@@ -80,5 +85,40 @@ def test_variation_matches_oracle(mgr, name):
     ok = np.zeros(N, bool)
     ok[fin] = (np.abs(d[fin] - r[fin]) <= 2e-4 + 2e-3 * np.abs(r[fin])).all(1)
     ok |= both_bad | (~fin & ~both_bad & (np.abs(r).max(1) >= 1e6))
-    frac = ok.mean()
-    assert frac >= 0.99, (name, frac, d[~ok][:3], r[~ok][:3])
+    def close(dv, rv):
+        if not np.isfinite(rv).all() or np.abs(rv).max() >= 1e6:
+            return not np.isfinite(dv).all() or np.abs(rv).max() >= 1e6
+        return bool((np.abs(dv - rv) <= 2e-4 + 2e-3 * np.abs(rv)).all())
+
+    def step(v, n):                                   # v moved by n float32 ulps
+        v = np.float32(v)
+        for _ in range(abs(n)):
+            v = np.nextafter(v, np.float32(np.inf if n > 0 else -np.inf), dtype=np.float32)
+        return float(v)
+
+    bad = np.nonzero(~ok)[0]
+    assert len(bad) <= 0.015 * N, (name, len(bad), d[bad][:3], r[bad][:3])
+    unexplained = []
+    for i in bad:
+        # the oracle over 7 x 7 inputs within 6 ulp of the point: at a discontinuity (floor / trunc / compare) or where
+        # the variation is ill-conditioned (popcorn's sin(tan(3y)) near a pole of tan: 1 ulp of y turns the sine by 0.1 rad)
+        # its own results spread further than the tolerance; on a well-conditioned point they agree to a few ulp and a
+        # wrong result fails
+        outs = []
+        for du in range(-6, 7, 2):
+            for dv in range(-6, 7, 2):
+                x, y, c = C.c_float(step(pts[i, 0], du)), C.c_float(step(pts[i, 1], dv)), C.c_float(pts[i, 2])
+                st = rng[i:i + 1].copy()
+                assert L.ref_apply_xf(rdr.packer.prog.ctypes.data, P.ctypes.data, 0, C.byref(x), C.byref(y), C.byref(c), st.ctypes.data) == 0
+                outs.append((x.value, y.value))
+        outs = np.array(outs, np.float64)
+        if not np.isfinite(outs).all() or np.abs(outs).max() >= 1e6:
+            continue                                   # the oracle itself leaves the finite range next to the point
+        # well-conditioned point: the 49 results agree to a few ulp and the spread adds nothing to the tolerance; at a jump
+        # the spread is the jump; where 1 ulp of input swings the result (sin(tan) next to a pole) the hardware's tan may
+        # land anywhere within that swing of libm's
+        spread = outs.max(0) - outs.min(0)
+        if not (np.isfinite(d[i]).all() and (np.abs(d[i] - r[i]) <= 2e-4 + 2e-3 * np.abs(r[i]) + spread).all()):
+            unexplained.append(int(i))
+    assert not unexplained, (name, 'points off the oracle at a well-conditioned input', unexplained[:5],
+                             pts[unexplained[:3]], d[unexplained[:3]], r[unexplained[:3]])

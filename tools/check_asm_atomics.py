@@ -1,49 +1,117 @@
 #!/usr/bin/env python3
 """k_accum_tiles issues the tile add's returning atomics and the record loop's loads from inline asm and waits for
-them itself (all of them, or all but the four newest loads); the compiler does not know the results are in flight, so
-nothing may touch a result register between its instruction and the wait.  The walk follows program text order and
-starts afresh after every unconditional branch (blocks placed out of line are entered from elsewhere).  This reads the device assembly (hipcc --cuda-device-only -S binned.hip) and checks exactly that.
-    python tools/check_asm_atomics.py /tmp/binned.s"""
-import re, sys
+them itself (all of them, or all but the newest loads); the compiler does not know the results are in flight, so
+nothing may touch a result register between its instruction and the wait.  This reads the device assembly
+(hipcc --cuda-device-only -S binned.hip, with the flags of the build) and checks exactly that.  The walk follows
+program text order (forward branches are not followed: everything in the text counts as executed, which is the
+feasible path of the pipelined loop from its second iteration on) and starts afresh after every unconditional
+branch (blocks placed out of line are entered from elsewhere); at every BACKWARD conditional branch — a loop's
+back-edge — the loop body is walked a second time with the state the first pass ended with, so that what stays in
+flight ACROSS iterations (the pipelined loop's second record set) meets the top of the loop again.
+(A walk of every path of the control-flow graph was tried: it reports the infeasible path that skips the
+`v0 != 0` wait in a later iteration.)
+    python tools/check_asm_atomics.py build/binned.s"""
+import re
+import sys
+
 lines = open(sys.argv[1]).read().split('\n')
-bad = n = 0
-kern = None
-pending = {}
-for ln in lines:
-    m = re.match(r'^(_Z\w+):', ln)
-    if m: kern, pending = m.group(1), {}
-    t = ln.strip()
-    if not t or t.startswith(';') or t.startswith('.') or t.endswith(':'): continue
-    if t.startswith('s_branch') or t.startswith('s_endpgm') or t.startswith('s_setpc'):
-        # what follows in the text is entered by jumps only (out-of-line rare paths): its predecessors' state is
-        # not known from text order, so the walk starts afresh there
-        pending = {}
-        continue
+ATOM = re.compile(r'global_atomic_add_x2 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off sc0')
+LOAD = re.compile(r'global_load_dword v(\d+), v(\d+), s\[(\d+):(\d+)\]$')          # the record loads of the pipelined loop (asm: no offset field)
+WAITN = re.compile(r's_waitcnt .*vmcnt\(([1-9]\d*)\)|s_waitcnt vmcnt\(([1-9]\d*)\)')
+LABEL = re.compile(r'^(\.LBB\d+_\d+):')
+FUNC = re.compile(r'^(_Z\w+):')
+
+
+def regs_of(t):
+    r = set()
+    for a, b in re.findall(r'v\[(\d+):(\d+)\]', t):
+        r.update(range(int(a), int(b) + 1))
+    r.update(int(x) for x in re.findall(r'\bv(\d+)\b', t))
+    return r
+
+
+def parse(t):
     if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
-        pending = {}
-        continue
-    regs = set()
-    for a, b in re.findall(r'v\[(\d+):(\d+)\]', t): regs.update(range(int(a), int(b) + 1))
-    regs.update(int(r) for r in re.findall(r'\bv(\d+)\b', t))
-    m = re.match(r'global_atomic_add_x2 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off sc0', t)
-    ml = re.match(r'global_load_dword v(\d+), v(\d+), s\[(\d+):(\d+)\]$', t)          # the record loads of the pipelined loop (asm: no offset field)
-    mw = re.match(r's_waitcnt vmcnt\(([1-9])\)$', t)
+        return ('wait0', None, None, t, None)
+    mw = WAITN.match(t)
     if mw:
-        # the pipelined loop's partial wait: the newest loads stay in flight
-        newest = [r for r, what in pending.items() if what.startswith('global_load_dword')][-int(mw.group(1)):]
-        pending = {r: pending[r] for r in newest}
+        return ('waitn', int(mw.group(1) or mw.group(2)), None, t, None)
+    ma, ml = ATOM.match(t), LOAD.match(t)
+    if ma or ml:
+        d = tuple(range(int(ma.group(1)), int(ma.group(2)) + 1)) if ma else (int(ml.group(1)),)
+        return ('atom' if ma else 'load', frozenset(regs_of(t)), d, t, None)
+    m = LABEL.match(t)
+    if m:
+        return ('label', None, None, t, m.group(1))
+    if t.startswith('s_branch') or t.startswith('s_endpgm') or t.startswith('s_setpc'):
+        return ('reset', None, None, t, None)
+    if t.startswith('s_cbranch'):
+        return ('cjump', None, None, t, t.split()[1])
+    return ('op', frozenset(regs_of(t)), None, t, None)
+
+
+def check_function(name, body):
+    """body: instruction / label lines of one function.  Returns (asm ops seen, violations)."""
+    ins = [parse(t) for t in body]
+    where = {i[4]: k for k, i in enumerate(ins) if i[0] == 'label'}
+    nops, bad = set(), set()
+
+    def walk(lo, hi, atoms, loads, second):
+        """Text-order walk of ins[lo:hi]; returns the state at the end."""
+        atoms, loads = set(atoms), list(loads)
+        for k in range(lo, hi):
+            kind, regs, dst, t, target = ins[k]
+            if kind == 'wait0':
+                atoms, loads = set(), []
+            elif kind == 'waitn':
+                loads = loads[-regs:]                   # the newest n loads stay in flight
+            elif kind == 'reset':
+                atoms, loads = set(), []
+            elif kind in ('atom', 'load'):
+                inflight = {r for a in atoms for r in a} | {r for l in loads for r in l}
+                hit = ((regs - set(dst)) & inflight) | (set(dst) & inflight)
+                if hit:
+                    bad.add('%s: %s touches in-flight v%s%s' % (name, t, sorted(hit), ' (second pass over a loop)' if second else ''))
+                (atoms.add(dst) if kind == 'atom' else loads.append(dst))
+                loads = loads[-16:]
+                nops.add(t)
+            elif kind == 'cjump':
+                # a loop's back-edge: once more over the body with what is in flight now
+                if not second and target in where and where[target] < k and (atoms or loads):
+                    walk(where[target], k, atoms, loads, True)
+            elif kind == 'op':
+                inflight = {r for a in atoms for r in a} | {r for l in loads for r in l}
+                hit = regs & inflight
+                if hit:
+                    bad.add('%s: "%s" touches v%s while its asm-issued load / atomic is in flight%s'
+                            % (name, t, sorted(hit), ' (second pass over a loop)' if second else ''))
+        return atoms, loads
+
+    walk(0, len(ins), set(), [], False)
+    return len(nops), sorted(bad)
+
+
+funcs, cur, name = [], [], None
+for ln in lines:
+    m = FUNC.match(ln)
+    if m:
+        if name:
+            funcs.append((name, cur))
+        name, cur = m.group(1), []
         continue
-    if m or ml:
-        d = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(ml.group(1))}
-        use = regs - d
-        hit = use & set(pending)
-        if hit or (d & set(pending)): bad += 1; print('%s: %s touches in-flight %s' % (kern, t, sorted(hit | (d & set(pending)))))
-        for r in d: pending[r] = t
-        n += 1
+    t = ln.strip()
+    if name is None or not t or t.startswith(';') or (t.startswith('.') and not LABEL.match(t)):
         continue
-    hit = regs & set(pending)
-    if hit:
-        bad += 1
-        print('%s: "%s" touches v%s, still in flight from "%s"' % (kern, t, sorted(hit), pending[min(hit)]))
-print('%d asm-issued returning atomics / record loads checked, %d violations' % (n, bad))
-sys.exit(1 if bad else 0)
+    cur.append(t)
+if name:
+    funcs.append((name, cur))
+n = 0
+violations = []
+for name, body in funcs:
+    k, bad = check_function(name, body)
+    n += k
+    violations += bad
+for v in violations[:40]:
+    print(v)
+print('%d asm-issued returning atomics / record loads checked (loop bodies twice), %d violations' % (n, len(violations)))
+sys.exit(1 if violations else 0)

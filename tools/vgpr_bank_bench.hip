@@ -50,12 +50,23 @@ __global__ void __launch_bounds__(256) k(float *out, float seed)
                          "v_pk_fma_f32 v[36:37], v[60:61], v[62:63], v[48:49]\n\tv_pk_fma_f32 v[38:39], v[50:51], v[52:53], v[54:55]\n\t"
                          "v_pk_fma_f32 v[40:41], v[56:57], v[58:59], v[60:61]\n\tv_pk_fma_f32 v[42:43], v[62:63], v[48:49], v[50:51]\n\t"
                          "v_pk_fma_f32 v[44:45], v[52:53], v[54:55], v[56:57]\n\tv_pk_fma_f32 v[46:47], v[58:59], v[60:61], v[62:63]" ::: CLOB);
+
+        else if (OP == 6)   // one step (two taps) of the DE tap loop, as compiled (de.hip, integer-step direction): 28 VALU + 2 v_exp_f32
+            asm volatile("v_fma_f32 v32, v48, v60, v49\n\tv_fma_f32 v33, v50, v60, v51\n\t"
+                         "v_fmac_f32 v32, v52, v61\n\tv_fmac_f32 v33, v53, v61\n\tv_fmac_f32 v32, v54, v62\n\tv_fmac_f32 v33, v55, v62\n\t"
+                         "v_fmac_f32 v32, v56, v63\n\tv_sub_f32 v34, v59, v57\n\tv_fmac_f32 v33, v58, v63\n\tv_sub_f32_e64 v32, v32, |v34|\n\t"
+                         "v_sub_f32 v34, v59, v47\n\tv_sub_f32_e64 v33, v33, |v34|\n\t"
+                         "v_exp_f32 v32, v32\n\tv_exp_f32 v33, v33\n\t"
+                         "v_mul_f32 v32, s4, v32\n\tv_mul_f32 v33, s5, v33\n\tv_mul_f32 v35, v46, v32\n\tv_mul_f32 v36, v45, v33\n\t"
+                         "v_add_f32 v37, v37, v32\n\tv_fma_f32 v38, v35, v56, v38\n\tv_fmac_f32 v39, v35, v54\n\tv_fma_f32 v40, v35, v52, v40\n\t"
+                         "v_add_f32 v41, v41, v35\n\tv_add_f32 v37, v33, v37\n\tv_fmac_f32 v38, v36, v58\n\tv_fmac_f32 v39, v36, v55\n\t"
+                         "v_fmac_f32 v40, v36, v53\n\tv_add_f32 v41, v36, v41" ::: CLOB, "s4", "s5");
     }
     float s;
     asm volatile("v_add_f32 %0, v32, v47" : "=v"(s) :: CLOB);
     if (s == 1.2345e-33f) out[0] = s;
 }
-template <int OP> static void run(const char *name, float *d, int ncu)
+template <int OP> static void run(const char *name, float *d, int ncu, double ninstr = 16.0)
 {
     const int wps = 8, blocks = ncu * wps;
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
@@ -64,7 +75,7 @@ template <int OP> static void run(const char *name, float *d, int ncu)
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
     hipEventRecord(e1, 0); hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-64s %6.3f ns per wave-instruction per SIMD (8 waves per SIMD)\n", name, ms / 5 * 1e6 / (LOOPS * 16.0 * wps));
+    printf("%-64s %6.3f ns per wave-instruction per SIMD (8 waves per SIMD)\n", name, ms / 5 * 1e6 / (LOOPS * ninstr * wps));
 }
 int main()
 {
@@ -77,5 +88,6 @@ int main()
     run<3>("v_fma_f32 accumulating (dst = addend), sources in two banks", d, p.multiProcessorCount);
     run<4>("v_add_f32, two sources in two banks", d, p.multiProcessorCount);
     run<5>("v_pk_fma_f32, register pairs", d, p.multiProcessorCount);
+    run<6>("DE tap step: 26 VALU + 2 v_exp_f32 (per instruction)", d, p.multiProcessorCount, 28.0);
     return 0;
 }
