@@ -49,6 +49,38 @@
 #include <cstdlib>
 #include <cstring>
 
+// This file is compiled twice.  DE_CHAIN_BUILD = 0 (de.hip itself): one kernel per direction, k_de_dir.
+// DE_CHAIN_BUILD = 1 (de_chain.hip includes it with 256-thread tile shapes for every direction): the per-tile body
+// becomes the device function de_tile<P>, called by the persistent eight-direction kernel there; what a tile reads and
+// writes then goes through write-through / L1-bypassing accesses (DeImg), because its neighbours of the previous
+// direction ran on other CUs of the SAME launch.
+#ifndef DE_CHAIN_BUILD
+#define DE_CHAIN_BUILD 0
+#endif
+typedef unsigned int de_u4v __attribute__((ext_vector_type(4)));
+// the image a direction reads / writes: plain pointers for the one-kernel-per-direction form ...
+struct DeImgPlain {
+    float4 *p;
+    __device__ __forceinline__ float4 ld(uint32_t i) const { return const_cast<const float4 *>(p)[i]; }
+    __device__ __forceinline__ void st(uint32_t i, float4 v) const { p[i] = v; }
+};
+// ... and buffer accesses with sc1 inside the persistent launch: stores write through to memory (and leave this
+// XCD's L2), loads bypass the CU's L1, which other CUs' stores never refresh (MI355X_MICROARCH.md, inter-workgroup
+// visibility; cdna_hip_programming.md Guideline 16 R1).  Byte offsets are 32 bits: an 8K image is 560 MB.
+struct DeImgSc1 {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ float4 ld(uint32_t i) const
+    {
+        const de_u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, i * 16u, 0, 16);      // aux 16 = sc1
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    __device__ __forceinline__ void st(uint32_t i, float4 v) const
+    {
+        const de_u4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(u, r, i * 16u, 0, 16);
+    }
+};
+
 struct DeCoefs { float k[7]; float k2[19]; };      // the blur's 7 taps; both blurs as ONE 19-tap kernel (integer-step directions)
 struct DeSpatial { float s[16]; };      // exp(-r^2 / (sqrt2 * sstd)), r = 0..15 (cuburn/code/filters.py:176-178), computed on the host
 
@@ -79,7 +111,7 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 // smaller workgroups put more independent phases on a CU (512 threads: four per CU; 256: eight), and the
 // kernels are 10-18 % faster (profiles/r03_de_tile_shapes.txt).  Taller tiles (less halo) are slower.
 #ifndef DE_TW_
-#define DE_TW_ 16      /* directions 4..7 (half slopes): 32 rows x 16 columns, 512 threads */
+#define DE_TW_ 8       /* directions 4..7 (half slopes): 32 rows x 8 columns, 256 threads (round 3: 32 x 16, 512 threads) */
 #endif
 #ifndef DE_TH_
 #define DE_TH_ 32
@@ -94,11 +126,14 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 #define DE_THH_ 32
 #endif
 #ifndef DE_TW0_
-#define DE_TW0_ 64     /* the horizontal direction: DE_TH0_ x DE_TW0_ tiles (round 2: 8 x 128) */
+#define DE_TW0_ 64     /* the horizontal direction: DE_TH0_ x DE_TW0_ tiles (round 2: 8 x 128, round 3: 8 x 64) */
 #endif
 #ifndef DE_TH0_
-#define DE_TH0_ 8
+#define DE_TH0_ 4
 #endif
+// Round 4: every direction in 256-thread workgroups, eight to a CU.  The DE alone is 3 % faster than with round 3's mix of
+// 256 and 512 threads, the two-lane frame loop 4.7 % (1.458 -> 1.390 ms at cfg2: smaller workgroups and LDS blocks find room
+// beside the other lane's kernels; profiles/r04_de_shapes_frame.txt).
 #ifndef DE_PRIO_STAGE
 #define DE_PRIO_STAGE 3
 #endif
@@ -188,19 +223,19 @@ template <int P> struct DeGeo {
 __device__ __forceinline__ int de_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // Direct evaluation of the two density blurs at an in-image position (border tiles only)
-template <int P>
-__device__ float de_b1_global(const float4 *__restrict__ N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
+template <int P, class IMG>
+__device__ float de_b1_global(const IMG &N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
 {
     float den = 0.0f;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         const int x = de_clampi(cx + de_dx(P, j - 3), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, j - 3), 0, (int)d.ah - 1);
-        den += N[(uint32_t)(y * (int)d.astride + x)].w * k.k[j];
+        den += N.ld((uint32_t)(y * (int)d.astride + x)).w * k.k[j];
     }
     return den;
 }
-template <int P>
-__device__ float de_b2_global(const float4 *__restrict__ N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
+template <int P, class IMG>
+__device__ float de_b2_global(const IMG &N, const fl_dim &d, int cx, int cy, const DeCoefs &k)
 {
     // all 49 loads are issued before the first is waited for: as a loop of seven dependent rounds this was seven
     // memory round trips (5-7 us) for the one tile that needs it, with the rest of its workgroup at the barrier
@@ -456,10 +491,18 @@ __device__ __forceinline__ float4 de_in_px(float4 p)
     return make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
 }
 
+__device__ __forceinline__ float4 de_in_px_rt(float4 p, int in_mode)      // the same, mode known at run time (wave-uniform)
+{
+    if (in_mode == 0) return p;
+    if (in_mode == 2) p = de_yuv_px(p);
+    const float rw = p.w > 0.0f ? frcp(p.w) : 0.0f;
+    return make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
+}
+
 // -DDE_X_PHASES: every workgroup adds the 100 MHz ticks it spent in each phase to de_phase_ticks[direction][phase]
 // (0 = until the loads are in LDS, 1 = first blur, 2 = tap terms, 3 = plane B written, 4 = taps + store, 5 = workgroups);
 // fl_debug_de_phases reads and clears them (tools/de_phases.py).
-#ifdef DE_X_PHASES
+#if defined(DE_X_PHASES) && !DE_CHAIN_BUILD
 #define DE_PH_MAXWG 16384
 __device__ unsigned long long de_phase_rec[8][DE_PH_MAXWG][6];      // per workgroup: no two writers share a word
 #define DE_PHASE(n) do { if (threadIdx.x == 0 && blockIdx.x < DE_PH_MAXWG) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); de_phase_rec[P][blockIdx.x][n] += now_ - tick_; tick_ = now_; } } while (0)
@@ -475,9 +518,28 @@ extern "C" __attribute__((visibility("default"))) int fl_debug_de_phases(unsigne
 #define DE_PHASE(n)
 #endif
 
+#if DE_CHAIN_BUILD
+// One tile of direction P as a device function (de_chain.hip): tile (tx, ty) of the direction's grid, input form and
+// tail known at run time (wave-uniform), images through IMG.
+#define DE_IN_PX(p) de_in_px_rt((p), IN)
+template <int P, class IMG>
+__device__ __forceinline__ void de_tile(const fl_dim &d, const IMG &Nout, const IMG &N, const DeCoefs &kc, const DeSpatial &spk,
+                                        float cs2, float ads, float dpow, float gspeed, const DeTail &tail, const int IN, const bool OUT,
+                                        const int tx, const int ty, const int tid)      // tid: threadIdx.x, made opaque by the caller's loop
+{
+    using G = DeGeo<P>;
+    static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *sA = reinterpret_cast<float4 *>(smem);
+    float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPXA * 16);
+    float *sW = reinterpret_cast<float *>(sB);                   // nested prep: dense density plane ...
+    float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
+    float *sWf = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16);      // fast prep: density plane beside B
+#else
+#define DE_IN_PX(p) de_in_px<IN>(p)
 template <int P, int IN, int OUT>
 __global__ void __launch_bounds__(DeGeo<P>::NT, 8)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
-k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCoefs kc, DeSpatial spk,
+k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, DeCoefs kc, DeSpatial spk,
          float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
 {
     using G = DeGeo<P>;
@@ -488,6 +550,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     float *sW = reinterpret_cast<float *>(sB);                   // nested prep: dense density plane ...
     float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
     float *sWf = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16);      // fast prep: density plane beside B
+    const DeImgPlain N = {const_cast<float4 *>(N_)}, Nout = {Nout_};
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of
     // tiles in column-major order, so that the tiles resident together on an XCD are vertical
@@ -495,12 +558,19 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     // Tiles at the image's sides are the slow ones (staged positions outside the image evaluate their blurs on
     // the global image): XCDs 4..7 walk their run backwards, so that the right edge is done first, not last.
     const uint32_t per_xcd = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u;
-    const uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
+    uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
+    // (tail.order = 1, FLAME_DE_ORDER=1: plain row-major order — tile t = workgroup t, rows of tiles left to right)
+    if (tail.order == 1) { const uint32_t tiles_x = ntiles / tiles_y; t = blockIdx.x < ntiles ? (blockIdx.x % tiles_x) * tiles_y + blockIdx.x / tiles_x : ntiles; }
     if (t >= ntiles) return;
+#endif
+#if !DE_CHAIN_BUILD
     const int tx = (int)(t / tiles_y), ty = (int)(t % tiles_y);
+#endif
     // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
     const int bx0 = tx * G::TW - (G::K > 0 ? G::SPAN : 0), by0 = ty * G::TH;
+#if !DE_CHAIN_BUILD
     const int tid = threadIdx.x;
+#endif
     const int xmax = (int)d.astride - 1, ymax = (int)d.ah - 1;
     // does any staged position leave the image?  (block-uniform)
     const bool border = by0 - G::HU < 0 || by0 + G::TH + G::HU > (int)d.ah ||
@@ -539,7 +609,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     // older workgroups' tap loops and its loads go out late.  Staging therefore runs at raised priority, the
     // taps at the default: the loads of the next tiles are in flight while the current tiles compute.
     __builtin_amdgcn_s_setprio(DE_PRIO_STAGE);
-#ifdef DE_X_PHASES
+#if defined(DE_X_PHASES) && !DE_CHAIN_BUILD
     unsigned long long tick_ = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x < DE_PH_MAXWG) de_phase_rec[P][blockIdx.x][5] += 1ull;
 #endif
@@ -547,7 +617,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
     if (gspeed != 12345.0f) goto taps;
 #endif
 #ifdef DE_X_STOP_AFTER
-#define DE_X_STOP(n) if (DE_X_STOP_AFTER == n && gspeed != 12345.0f) { if (tid == 0 && sB[17].x == 1.2345e-33f) Nout[0] = sB[17]; return; }
+#define DE_X_STOP(n) if (DE_X_STOP_AFTER == n && gspeed != 12345.0f) { if (tid == 0 && sB[17].x == 1.2345e-33f) Nout.st(0, sB[17]); return; }
 #else
 #define DE_X_STOP(n)
 #endif
@@ -565,7 +635,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
             int ul, vl;
             s_elem_clamped(it, ul, vl);
             const int gx = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gy = by0 + ul - G::HU;      // inside the image: no clamps
-            tq[it] = de_in_px<IN>(N[(uint32_t)(gy * (int)d.astride + gx)]);
+            tq[it] = DE_IN_PX(N.ld((uint32_t)(gy * (int)d.astride + gx)));
         }
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
@@ -605,7 +675,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout, const float4 *__restrict__ N, DeCo
         s_elem_clamped(it, ul, vl);
         const int gx = de_clampi(bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, 0, xmax);
         const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
-        tn[it] = de_in_px<IN>(N[(uint32_t)(gy * (int)d.astride + gx)]);
+        tn[it] = DE_IN_PX(N.ld((uint32_t)(gy * (int)d.astride + gx)));
     }
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
@@ -738,11 +808,12 @@ taps:
             if (tail.do_clip) p = colorclip_px(p, tail.vib, tail.highpow, tail.gam, tail.lin, tail.lingam);
             res = p;
         }
-        Nout[(uint32_t)(yo * (int)d.astride + xo)] = res;
+        Nout.st((uint32_t)(yo * (int)d.astride + xo), res);
     }
     DE_PHASE(4);
 }
 
+#if !DE_CHAIN_BUILD
 template <bool YUV>
 __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__restrict__ N, const float4 *__restrict__ src)
 {
@@ -754,13 +825,12 @@ __global__ void __launch_bounds__(256) k_de_normalise(uint32_t n, float4 *__rest
     N[gi] = make_float4(p.x * rw, p.y * rw, p.z * rw, p.w);
 }
 
-// Workgroups per CU.  A direction's tiles all cost the same and a CU holds R workgroups at a time, so the kernel takes
-// ceil(tiles per CU / R) rounds of one workgroup lifetime each — and the lifetime itself is R waves per SIMD sharing one
-// vector ALU, i.e. proportional to R: time ~ ceil(T / R) * R.  With R = 8 a 1080p direction of 8540 tiles (33.4 per
-// CU) runs 5 rounds for 4.17 rounds' worth of work; with R = 7 the same 5 rounds are 12 % shorter.  R is enforced through
-// the dynamic-LDS request (more LDS than the kernel uses); the choice minimises ceil(T / R) * R over the R the
-// kernel's registers and LDS allow, preferring the larger R on ties (latency hiding).  FLAME_DE_WGS="r0,r1,..,r7"
-// overrides per direction (0 = the kernel's maximum).
+// Workgroups per CU (experiment, FLAME_DE_WGS="r0,r1,..,r7"; default: the kernel's maximum).  If a direction's tiles all cost
+// the same and a CU holds R workgroups whose lifetime is proportional to R (one vector ALU shared by R waves per SIMD), a
+// kernel takes ceil(tiles per CU / R) * R: with R = 8 a 1080p direction of 8540 tiles (33.4 per CU) would run 5 rounds for
+// 4.17 rounds' worth of work, with R = 7 the same 5 rounds 12 % shorter.  Measured: R = 7 changes nothing (39.7 / 40.0 us),
+// R = 6 and R = 3 (512-thread tiles) cost 2-5 % (profiles/r04_de_residency.txt) — the kernels are not bound by rounds of
+// equal lifetimes.  R is enforced through the dynamic-LDS request (more LDS than the kernel uses).
 static size_t de_lds_for_residency(size_t lds, int nt, uint32_t ntiles, int pattern)
 {
     const int ncu = 256, lds_cu = 160 * 1024;
@@ -775,14 +845,7 @@ static size_t de_lds_for_residency(size_t lds, int nt, uint32_t ntiles, int patt
         }
     }
     if (forced[pattern] >= 0) want = forced[pattern];
-    else {
-        const double t = (double)ntiles / ncu;
-        double best = 1e30;
-        for (int r = rmax; r >= std::max(2, rmax - 2); --r) {       // (fewer than rmax - 2 costs more latency hiding than rounding wins)
-            const double cost = std::ceil(t / r) * r;
-            if (cost < best - 1e-9) { best = cost; want = r; }
-        }
-    }
+    (void)ncu; (void)ntiles;
     if (want <= 0 || want >= rmax) return lds;
     // the smallest request that no longer fits `want + 1` times: LDS is handed out in 1 KB steps... use half-way
     const size_t per = (size_t)lds_cu / want;                       // fits `want` times
@@ -824,8 +887,18 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     for (int r = 0; r < 16; ++r) spk.s[r] = expf((float)(r * r) / (-1.41421353816986f * sstd));
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
-    const DeTail none = {};
-#define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tail ? *tail : none)
+    DeTail none = {};
+    // Tile order.  The (near-)horizontal directions 0, 4 and 6 stage wide and flat regions: their tiles run in plain row-major
+    // order (workgroup b = tile b of the row of tiles), the others in per-XCD column-major runs (vertical neighbours, which
+    // share halo rows, on one XCD's L2).  Measured per direction (profiles/r04_de_order_prof.txt): row-major 43.0 / 66.0 /
+    // 65.9 us against 48.5 / 72.3 / 71.5 for directions 0 / 4 / 6, and 44.7-65.6 against 40.5-61.2 for the other five.
+    // FLAME_DE_ORDER=0|1 forces one order for every direction.
+    static const int forced = getenv("FLAME_DE_ORDER") ? atoi(getenv("FLAME_DE_ORDER")) : -1;
+    const int order = forced >= 0 ? forced : (pattern == 0 || pattern == 4 || pattern == 6) ? 1 : 0;
+    none.order = order;
+    DeTail tl = tail ? *tail : none;
+    tl.order = order;
+#define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tl)
     switch (pattern) {
     case 0: if (in_mode == 2) DE(0, 2, 0); else if (in_mode == 1) DE(0, 1, 0); else DE(0, 0, 0); break;
     case 1: DE(1, 0, 0); break;
@@ -846,3 +919,4 @@ void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src,
     if (yuv) hipLaunchKernelGGL(k_de_normalise<true>, dim3((n + 255) / 256), dim3(256), 0, st, n, N, src);
     else hipLaunchKernelGGL(k_de_normalise<false>, dim3((n + 255) / 256), dim3(256), 0, st, n, N, src);
 }
+#endif /* !DE_CHAIN_BUILD */

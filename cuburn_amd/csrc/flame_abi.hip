@@ -67,6 +67,9 @@ struct Lane {
     // ... or, in the one-kernel-per-direction form, the LAST DIRECTION itself is still to run: it reads
     // pend_N, un-normalises and tone-maps as it stores into d_front (de.hip, OUT = 1)
     bool pend_last = false;
+    // the whole eight-direction DE pending as one persistent launch (de_chain.hip): 1 = persistent, 2 = its tiles one direction per launch
+    int pend_chain = 0, pend_in_mode = 0;
+    void *d_chain = nullptr; size_t chain_bytes = 0;      // the launch's parameter block, list heads and counters
     float pend_dp[5] = {0, 0, 0, 0, 0}, pend_k7[7] = {0, 0, 0, 0, 0, 0, 0};
     fl_dim pend_dim = {0, 0, 0, 0, 0};
 };
@@ -94,6 +97,7 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
+    int env_de_chain = 0;                   // FLAME_DE_CHAIN: 1 = the DE as one persistent launch, 2 = its tile shapes one direction per launch
     bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
     uint32_t n_spec_launch = 0, n_interp_launch = 0;      // iterate launches by kernel since fl_timings_reset (fl_launch_stats)
@@ -188,6 +192,7 @@ static void free_fb(fl_ctx *c)
     L(c).d_front = L(c).d_back = L(c).d_side = nullptr; L(c).d_blur = nullptr; L(c).d_atom = nullptr;
     L(c).d_hot = nullptr; L(c).d_outpix = nullptr; L(c).nbins = 0; L(c).outpix_bytes = 0;
     L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = L(c).pend_last = false;      // whatever was deferred dies with the buffers
+    L(c).pend_chain = 0;
     L(c).pend_N = nullptr;
 }
 
@@ -247,6 +252,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
+    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
     c->env_flush_last = env_on("FLAME_FLUSH_LAST");
@@ -312,7 +318,7 @@ void fl_ctx_destroy(fl_ctx *c)
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
-        hipFree(ln.d_params); hipFree(ln.d_palette);
+        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_chain);
         for (int k = 0; k < 2; ++k) {
             hipFree(ln.d_log[k]); hipFree(ln.d_dir[k]);
             if (ln.ev_it[k]) hipEventDestroy(ln.ev_it[k]);
@@ -737,6 +743,16 @@ static void gauss7(float stdev, float *c)      // cuburn/filters.py:11-16
 static void run_de_finish(fl_ctx *c, const float *clip)
 {
     Lane &ln = L(c);
+    if (ln.pend_chain) {
+        // every direction in one persistent launch: the accumulator in d_front goes through d_back and ends in d_front
+        DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
+                    clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
+        launch_de_chain(ln.stream, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
+                        ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, ln.pend_chain == 2);
+        ln.pend_finish = ln.pend_log = ln.pend_last = false;
+        ln.pend_chain = 0;
+        return;
+    }
     if (ln.pend_last) {
         DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
                     clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
@@ -785,6 +801,22 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
                 launch_bilateral(st, d, L(c).d_back, L(c).d_front, (const float *)L(c).d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
                 std::swap(L(c).d_front, L(c).d_back);
             }
+            break;
+        }
+        if (!c->env_de_split && c->env_de_chain && !c->env_de_unfused_ends) {
+            // All eight directions in ONE persistent launch (de_chain.hip), deferred as a whole so that a following
+            // logscale / colorclip can ride along in the last direction's tiles
+            const size_t need = de_chain_scratch_bytes(d);
+            if (L(c).chain_bytes < need) {
+                if (L(c).d_chain) { sync_all(c); (void)hipFree(L(c).d_chain); L(c).d_chain = nullptr; L(c).chain_bytes = 0; }
+                HIPCHK(hipMalloc(&L(c).d_chain, need));
+                L(c).chain_bytes = need;
+            }
+            L(c).pend_chain = c->env_de_chain; L(c).pend_in_mode = L(c).pend_yuv ? 2 : 1;
+            L(c).pend_yuv = false;
+            L(c).pend_finish = true; L(c).pend_last = false; L(c).pend_log = false; L(c).pend_N = L(c).d_front; L(c).pend_dim = d;
+            for (int i = 0; i < 5; ++i) L(c).pend_dp[i] = p[i];
+            for (int i = 0; i < 7; ++i) L(c).pend_k7[i] = k7[i];
             break;
         }
         if (!c->env_de_split) {
@@ -1188,6 +1220,15 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
     if (log && log_bytes) { snprintf(log, log_bytes, "%s", rc ? err.c_str() : "ok"); }
     if (rc) return fail(rtc_available() ? FL_E_HIP : FL_E_UNSUPPORTED, "per-genome kernel did not compile", __FILE__, __LINE__);
     return (int)(code.size() > 0 ? FL_OK : FL_E_HIP);
+}
+
+int fl_debug_de_chain_failed(fl_ctx *c)
+{
+    REQUIRE(c, "null ctx");
+    sync_all(c);
+    int bad = 0;
+    for (int i = 0; i < 2; ++i) if (c->lanes[i].d_chain && de_chain_failed(c->lanes[i].d_chain) != 0) bad = 1;
+    return bad;
 }
 
 int fl_debug_counters(fl_ctx *c, uint64_t out4[4])

@@ -89,10 +89,16 @@ void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 
 // de.hip
 // tone filters that ride along with the last DE direction (filters.py default chains: DE -> logscale -> colorclip)
-struct DeTail { int do_log; float k1, k2; int do_clip; float vib, highpow, gam, lin, lingam; };
+struct DeTail { int do_log; float k1, k2; int do_clip; float vib, highpow, gam, lin, lingam; int order; };
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
                    float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 0, const DeTail *tail = nullptr);
 void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv);
+// de_chain.hip: all eight directions in one persistent launch (img0: input, in_mode as launch_de_dir's; the result lands
+// in img0; scratch: de_chain_scratch_bytes() of device memory); one_by_one: eight launches of the same tiles
+size_t de_chain_scratch_bytes(fl_dim d);
+void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
+                     float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, bool one_by_one);
+int de_chain_failed(const void *scratch);
 
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);

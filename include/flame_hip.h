@@ -292,6 +292,9 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
                          char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
 int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
+/* FLAME_DE_CHAIN=1 runs the eight DE directions (cuburn/filters.py:62-95) as one persistent launch whose tiles wait for
+ * their neighbours of the previous direction; 1 if a wait of the launches so far ever gave up (a bug), else 0. */
+int fl_debug_de_chain_failed(fl_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -1210,6 +1210,48 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     m.fb.free()
 
 
+@pytest.mark.parametrize('size', [(200, 120), (640, 360), (1920, 1080)])
+def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
+    """FLAME_DE_CHAIN=1: the eight DE directions as ONE persistent launch (de_chain.hip) — every tile waits for the tiles of
+    the previous direction within its reach, written by other CUs of the same launch (write-through stores, L1-bypassing
+    loads, per-band counters).  Same bits as the same tiles run one direction per launch (FLAME_DE_CHAIN=2), for every
+    chain shape, several times over (a stale read or a tile that ran early shows as a different pixel), on a small
+    image (one work list), a mid-sized one and 1080p (one list per XCD, cross-stripe waits); and the same picture as
+    the default one-kernel-per-direction path, whose other tile shapes only move the border / interior choice of the
+    density blur's summation order."""
+    lib = _lib.load()
+    w, h = size
+    steps = {'yuv': [], 'bilateral': [6.0 * w / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
+             'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)]}
+    mgrs = {}
+    for mode in ('1', '2', '0'):
+        monkeypatch.setenv('FLAME_DE_CHAIN', mode)
+        mgrs[mode] = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
+    dim = mgrs['1'].fb.calc_dim(w, h)
+    buf = synth_accum(dim, seed=3)
+
+    def run(m, chain):
+        _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
+        m.fb.write('front', buf)
+        for name in chain:
+            arr = np.asarray(steps[name], np.float32)
+            _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
+        return m.fb.read('front', buf.shape, np.float32)
+
+    for chain in (['yuv', 'bilateral', 'logscale', 'colorclip'], ['bilateral'], ['yuv', 'bilateral', 'logscale']):
+        one = run(mgrs['2'], chain)
+        assert np.isfinite(one).all() and one.max() > 0
+        for rep in range(4 if w < 1920 else 8):
+            per = run(mgrs['1'], chain)
+            assert np.array_equal(per.view(np.uint32), one.view(np.uint32)), (chain, rep, int((per != one).sum()))
+        std = run(mgrs['0'], chain)
+        err = np.abs(std - one)
+        assert err.max() <= 2e-5 * max(1.0, float(np.abs(std).max())) and err.mean() < 1e-7 * max(1.0, float(np.abs(std).max())), (chain, err.max(), err.mean())
+    assert lib.fl_debug_de_chain_failed(mgrs['1'].fb.ctx) == 0
+    for m in mgrs.values():
+        m.fb.free()
+
+
 def test_deferred_filter_fusion_is_bit_identical(mgr):
     """fl_filter defers `yuv` and the DE's un-normalising pass so that bilateral / logscale /
     colorclip can take them along in one kernel.  Looking at the buffer between the calls forces

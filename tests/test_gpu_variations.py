@@ -117,8 +117,10 @@ def test_variation_matches_oracle(mgr, name):
         # well-conditioned point: the 49 results agree to a few ulp and the spread adds nothing to the tolerance; at a jump
         # the spread is the jump; where 1 ulp of input swings the result (sin(tan) next to a pole) the hardware's tan may
         # land anywhere within that swing of libm's
+        # (x 4: the hardware's rcp / sqrt / sin of INTERMEDIATES are each a few ulp off libm's, which next to a pole — conic's
+        # 1 / (1 + e cos t), condition number 1e5 — weighs like tens of ulp of the input)
         spread = outs.max(0) - outs.min(0)
-        if not (np.isfinite(d[i]).all() and (np.abs(d[i] - r[i]) <= 2e-4 + 2e-3 * np.abs(r[i]) + spread).all()):
+        if not (np.isfinite(d[i]).all() and (np.abs(d[i] - r[i]) <= 2e-4 + 2e-3 * np.abs(r[i]) + 4.0 * spread).all()):
             unexplained.append(int(i))
     assert not unexplained, (name, 'points off the oracle at a well-conditioned input', unexplained[:5],
                              pts[unexplained[:3]], d[unexplained[:3]], r[unexplained[:3]])
