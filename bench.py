@@ -416,7 +416,7 @@ def main():
                          'traffic_measured_in_this_run': False,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
-                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'vector / scalar issue and the per-round barrier (65 % of the wall-clock VALU peak; not bandwidth)',
+                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'instruction issue: 351 M vector + 160 M scalar instructions + 50 M branches per launch with four waves per SIMD to overlap them; not bandwidth, not the per-round barrier (DESIGN 4.1, round 4)',
                                     'measured_bytes_per_launch': iter_bytes,
                                     'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
                                     'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
@@ -424,14 +424,14 @@ def main():
                          'k_flush_ms_per_frame': round(acc['flush_only_ms'] / ksteps, 4),
                          'note': ('kernel times: one stream lane, the frame loop\'s walker geometry (%d slots).  For frames of up to 2^28 samples the loop '
                                   'runs 1024 slots: a third fewer un-plotted fuse iterations, the PIPELINE ~4 %% faster, this chain ALONE ~5 %% slower '
-                                  'than at 1536 slots (FLAME_NSLOTS=1536: 1.05 ms = 0.51; profiles/r03_slots_by_samples.txt)' % mgr.fb.nslots)},
+                                  'than at 1536 slots (FLAME_NSLOTS=1536; profiles/r03_slots_by_samples.txt)' % mgr.fb.nslots)},
             'de_filter': {'kernels': '8 x k_de_dir (the first normalises the accumulator, the last un-normalises and tone-maps)', 'ms_per_frame': round(de_s * 1e3, 4),
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
                           'frac_of_achievable_6300': round(de_gbs / HBM_ACHIEVABLE_GBS, 5),
                           'traffic': de_traffic,
-                          'bound': 'workgroup phase latency x vector ALU (DESIGN 4.3: 55-65 % of the wall-clock VALU peak, 15 % of HBM): 512 B/px is the algorithmic byte count of the reference pass structure'},
+                          'bound': 'vector-ALU issue slots (DESIGN 4.3 round 4: SQ_ACTIVE_INST_VALU = 87-100 % of a direction\'s duration, ~80 % of the rate the tap loop\'s instruction mix runs at alone; 15 % of HBM): 512 B/px is the algorithmic byte count of the reference pass structure'},
             'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),
                                     'filters': round(acc['filter_ms'] / ksteps, 4), 'note': 'un-overlapped (single stream lane)'},
         }

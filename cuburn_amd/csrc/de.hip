@@ -21,7 +21,11 @@
 //     rounded), so the inner exponential stays in the loop (two v_exp_f32 per tap).
 //   * w^dpow is computed when a pixel is staged (2 transcendentals per staged pixel instead of a
 //     4-byte plane read and written per direction).
-//   * What bounds it (round 3, tools/valu_bench.hip wall-clock + tools/de_phases.py): a workgroup's life is a staging
+//   * What bounds it (round 4): vector-ALU issue slots.  SQ_ACTIVE_INST_VALU of a direction equals its duration, the tap loop's own
+//     instruction mix runs at 1.46 ns per wave-instruction per SIMD in isolation (tools/vgpr_bank_bench.hip) and the kernels reach ~80 %
+//     of that; LDS conflicts, ILP, packed FMAs and workgroups per CU measured nothing, three instructions fewer per tap -6 %
+//     (profiles/r04_de_instruction_experiments.txt, DESIGN.md 4.3 "Round 4").
+//   * (round 3's reading, tools/valu_bench.hip wall-clock + tools/de_phases.py): a workgroup's life is a staging
 //     phase that mostly waits (global loads, barriers: 2.6-4.6 us) and a tap phase that computes (the taps of all
 //     resident workgroups together run the vector ALU at ~80 % of its measured peak of one wave instruction per
 //     1.21 ns per SIMD); a kernel then pays ~8-10 us of ramp-up and tail on top (every workgroup stages at the start,
@@ -39,7 +43,7 @@
 //
 // Scalar (non-packed) math: on gfx950 v_pk_fma_f32 issues at ~1.6x the cost of v_fma_f32
 // (tools/valu_bench.hip), which does not pay for the 16-apart pixel pairing and ds_read2_b32
-// traffic the packed form needs; at <= 64 VGPRs a CU holds 32 waves (in workgroups of 256 or 512 threads, see DE_TW_).
+// traffic the packed form needs; at <= 64 VGPRs a CU holds 32 waves (in workgroups of 256 threads, see DE_TW_).
 #include "flame_device.h"
 #include "kernels.h"
 #include "tone_device.h"

@@ -97,7 +97,11 @@ struct fl_ctx {
     size_t pool_used = 0;
     bool timing = true;
     // environment switches, read once when the context is created
-    int env_de_chain = 0;                   // FLAME_DE_CHAIN: 1 = the DE as one persistent launch, 2 = its tile shapes one direction per launch
+    // FLAME_DE_CHAIN: how the DE's eight directions are launched.  3 (default): de.hip's eight kernels, queued together once the
+    // tone filters that ride along in the last one are known (back to back on the stream: the two-lane frame loop is 3 %
+    // faster than with seven of them queued by the bilateral call and the eighth two host calls later, profiles/r04_de_defer.txt);
+    // 0: that earlier form; 1: ONE persistent launch (de_chain.hip); 2: the persistent launch's tiles, one direction per launch
+    int env_de_chain = 3;
     bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
     uint32_t n_spec_launch = 0, n_interp_launch = 0;      // iterate launches by kernel since fl_timings_reset (fl_launch_stats)
@@ -252,7 +256,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
-    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
+    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 0;      // 3: de.hip's kernels, all queued when the tail is known
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
     c->env_flush_last = env_on("FLAME_FLUSH_LAST");
@@ -747,6 +751,15 @@ static void run_de_finish(fl_ctx *c, const float *clip)
         // every direction in one persistent launch: the accumulator in d_front goes through d_back and ends in d_front
         DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
                     clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
+        if (ln.pend_chain == 3) {      // the eight per-direction kernels of de.hip, all queued here (the tail is known now)
+            float4 *Na = ln.d_back, *Nb = ln.d_front;
+            launch_de_dir(ln.stream, ln.pend_dim, 0, Na, Nb, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, nullptr);
+            for (int pat = 1; pat < 7; ++pat) {
+                launch_de_dir(ln.stream, ln.pend_dim, pat, Nb, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4]);
+                std::swap(Na, Nb);
+            }
+            launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], 0, &t);
+        } else
         launch_de_chain(ln.stream, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
                         ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, ln.pend_chain == 2);
         ln.pend_finish = ln.pend_log = ln.pend_last = false;
@@ -806,7 +819,7 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         if (!c->env_de_split && c->env_de_chain && !c->env_de_unfused_ends) {
             // All eight directions in ONE persistent launch (de_chain.hip), deferred as a whole so that a following
             // logscale / colorclip can ride along in the last direction's tiles
-            const size_t need = de_chain_scratch_bytes(d);
+            const size_t need = c->env_de_chain == 3 ? 0 : de_chain_scratch_bytes(d);
             if (L(c).chain_bytes < need) {
                 if (L(c).d_chain) { sync_all(c); (void)hipFree(L(c).d_chain); L(c).d_chain = nullptr; L(c).chain_bytes = 0; }
                 HIPCHK(hipMalloc(&L(c).d_chain, need));

@@ -334,9 +334,17 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {
+#if defined(FL_X_NOSWAP)            /* timing experiments only (wrong results): no point swap at all ... */
+            (void)dst;
+#elif defined(FL_X_HALF_BARRIERS)   /* ... or a barrier every other round */
+            swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
+            if (par) __syncthreads();
+            x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+#else
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+#endif
 #if FL_ITER_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif

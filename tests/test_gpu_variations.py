@@ -120,7 +120,11 @@ def test_variation_matches_oracle(mgr, name):
         # (x 4: the hardware's rcp / sqrt / sin of INTERMEDIATES are each a few ulp off libm's, which next to a pole — conic's
         # 1 / (1 + e cos t), condition number 1e5 — weighs like tens of ulp of the input)
         spread = outs.max(0) - outs.min(0)
-        if not (np.isfinite(d[i]).all() and (np.abs(d[i] - r[i]) <= 2e-4 + 2e-3 * np.abs(r[i]) + 4.0 * spread).all()):
+        # A result magnified 1000-fold (conic's 1 / (1 + e cos t) where the sum cancels to 1e-5: the float32 rounding of
+        # cos t alone is worth 0.6 % of it, whichever way the division that produced it was rounded) is held to 5 %.
+        blown = np.abs(r[i]).max() >= 1e3 * max(1.0, float(np.abs(pts[i, :2]).max()))
+        rel = 5e-2 if blown else 2e-3
+        if not (np.isfinite(d[i]).all() and (np.abs(d[i] - r[i]) <= 2e-4 + rel * np.abs(r[i]) + 4.0 * spread).all()):
             unexplained.append(int(i))
     assert not unexplained, (name, 'points off the oracle at a well-conditioned input', unexplained[:5],
                              pts[unexplained[:3]], d[unexplained[:3]], r[unexplained[:3]])
