@@ -132,6 +132,32 @@ __device__ __forceinline__ void spec_apply_xf(const XfHead &h, const float *__re
     x = ox; y = oy;
 }
 
+// Kernels of few xforms keep EVERY xform's record in scalar registers for the whole launch (a slot's parameter block
+// does not change during a launch): the round then neither computes the next record's address nor loads it (three
+// scalar ALU instructions, up to five s_load and their share of the round's lgkmcnt waits — the scalar unit is on this
+// kernel's critical path).  Nine registers per xform (pre affine, colour, speed, first weight; six more with a post affine).
+#ifndef FL_RESIDENT_MAX_XF
+#define FL_RESIDENT_MAX_XF 4
+#endif
+__host__ __device__ constexpr int spec_resident_sgprs()
+{
+    int n = 0;
+    for (int i = 0; i < FL_SPEC_NXF; ++i) n += 9 + (kSpecPost[i] != 0 ? 6 : 0);
+    return n;
+}
+constexpr bool kSpecResident = FL_SPEC_NXF <= FL_RESIDENT_MAX_XF && spec_resident_sgprs() <= 48;
+template <int LO, int HI>
+__device__ __forceinline__ void spec_dispatch_res(int k, const XfHead (&heads)[FL_SPEC_NXF], const float *__restrict__ xf0, int xf_stride,
+                                                  float &x, float &y, float &c, mwc_t &r)
+{
+    if constexpr (HI - LO == 1) spec_apply_xf<LO>(heads[LO], xf0 + LO * xf_stride, x, y, c, r);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, xf0, xf_stride, x, y, c, r);
+        else spec_dispatch_res<MID, HI>(k, heads, xf0, xf_stride, x, y, c, r);
+    }
+}
+
 // wave-uniform dispatch over the selectable xforms [LO, HI): a binary tree of scalar compares
 template <int LO, int HI>
 __device__ __forceinline__ void spec_dispatch(int k, const XfHead &h, const float *__restrict__ xf,
@@ -299,7 +325,17 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     uint32_t sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
     int k_next = choose(sel_next);
     const float *__restrict__ xf_next = P + xf_off + k_next * xf_stride;
-    XfHead hnext = load_head(xf_next);
+#ifdef FL_RTC
+    constexpr bool RESIDENT = SPEC && kSpecResident;
+    XfHead heads[FL_SPEC_NXF];
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < FL_SPEC_NXF; ++i) heads[i] = load_head(P + xf_off + i * xf_stride);
+    }
+#else
+    constexpr bool RESIDENT = false;
+#endif
+    XfHead hnext = RESIDENT ? XfHead{} : load_head(xf_next);
 
     // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
     uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
@@ -325,12 +361,13 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // on this kernel's critical path) and still has the swap, the barrier and the rest of the round to
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
-        if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
+        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, P + xf_off, xf_stride, x, y, color, rctx);
+        else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
 #endif
         apply_xf(hnext, xf_cur, var_stride, x, y, color, rctx);
-        hnext = load_head(xf_next);
-        (void)k_cur;
+        if constexpr (!RESIDENT) hnext = load_head(xf_next);
+        (void)k_cur; (void)xf_cur;
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity
         {

@@ -14,7 +14,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 lib = _lib.load()
 m = render.RenderManager(device=0, nslots=1024, host_seed=7)
 worst = []
-for k in range(cases):
+only = [int(v) for v in os.environ['SOAK_ONLY'].split(',')] if os.environ.get('SOAK_ONLY') else None
+for k in (only or range(cases)):
     rs = np.random.RandomState(7000 + k)
     w, h = int(rs.choice([96, 161, 320, 480, 641])), int(rs.choice([64, 97, 180, 270, 359]))
     dim = m.fb.set_dim(w, h); d = O.calc_dim(w, h)
