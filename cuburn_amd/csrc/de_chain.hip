@@ -23,6 +23,13 @@
 //
 // The same tile shapes are also available one direction per launch (k_de_one) so that the persistent launch can be
 // compared bit for bit with eight launches of the same arithmetic.
+//
+// Measured (profiles/r04_de_chain.txt, r04_de_lap.txt): 950-970 us against 440-460 for eight plain launches.  Most of the loss is
+// the list heads: 8540 RETURNING agent-scope atomics per head queue up at ~55 ns each, so a workgroup waits ~12 us for every item
+// (a static assignment — workgroup w takes items w, w + 256, ... — runs the chain in 547 us, but two such launches from the two
+// lanes, each partly resident, wait for each other's missing workgroups: the frame loop stalls until the waits give up; removed
+// again).  The overlapped launches at the end of this file get the same overlap between directions from the hardware's own
+// in-order dispatch.
 #define DE_CHAIN_BUILD 1
 #define DE_TW_ 8        /* directions 4..7: 32 x 8 */
 #define DE_TWE_ 8
@@ -73,6 +80,12 @@ struct ChParams {
     uint32_t *fail;                 // set when a wait gives up (a bug, never expected)
     uint32_t tiles_x[8], tiles_y[8];
     uint32_t x0[8][9];              // first tile column of stripe s of direction p (x0[p][nstripes] = tiles_x[p])
+    // overlapped launches (k_de_lap): nothing is cleared between chains — a tile is finished when its flag holds the chain's
+    // epoch, a direction has been dispatched completely when its (ever-growing) count of started workgroups says so
+    uint32_t epoch, maxtiles;
+    uint32_t dbg;                   // FLAME_DE_LAP_DBG, timing experiments (wrong results): 1 no waits, 2 no publishing, 4 one stream and no gates, 8 no started count, 16 plain loads / stores
+    uint32_t *flags;                // [8][maxtiles] epoch of the last chain in which tile t of direction p finished
+    unsigned long long *started;    // [8][CH_NCNT] (one 64-byte line each) workgroups of direction p started since the scratch was allocated
 };
 __global__ void k_ch_params(ChParams *dst, ChParams v) { if (threadIdx.x == 0) *dst = v; }
 
@@ -230,6 +243,107 @@ __global__ void __launch_bounds__(CH_NT, 8) k_de_one(const ChParams *__restrict_
     ch_run<P, DeImgPlain>(q, src, dst, (int)(t % q->tiles_x[P]), (int)(t / q->tiles_x[P]), (int)threadIdx.x);
 }
 
+// ---- Overlapped launches (FLAME_DE_CHAIN=4): one launch per direction again, but direction p + 1 starts while the last
+// round of direction p's workgroups is still running, and fills the compute units they leave.
+//   * Directions alternate between two streams.  In front of direction p + 1 its stream runs k_de_gate, one wave that
+//     waits until EVERY workgroup of direction p has started (hipExtAnyOrderLaunch is ignored on gfx950 and two kernels
+//     simply co-dispatched could deadlock: waiting workgroups of p + 1 holding the slots p's remaining tiles need.
+//     Once all of p's workgroups are resident, whatever p + 1 waits for is running, and by induction finishes).
+//     tools/lap_probe.hip: the hand-over costs nothing measurable, hipStreamWaitValue64 does the same.
+//   * Tiles in row-major order: p + 1 begins at the top of the image while p finishes the bottom, so the waits below
+//     practically never spin.
+//   * A tile of p + 1 waits for the flags of p's tiles within reach (same reach arithmetic as the persistent launch: read
+//     after write for its staged region, write after read for its output, the two images ping-pong); hand-off as there:
+//     write-through stores, L1-bypassing loads, drain + barrier, then the flag (cdna_hip_programming.md Guideline 16, R1).
+// The started-workgroup count of a direction is spread over CH_NCNT words in separate 64-byte lines: agent-scope atomics
+// on ONE address complete at ~18 M/s (8540 workgroups: 470 us — the first form of this kernel, and of the persistent launch's
+// list heads, profiles/r04_de_lap.txt), and the workgroup's first wave waits for it with its loads (one in-order counter).
+typedef __attribute__((address_space(1))) unsigned long long *ChG64;
+constexpr int CH_NCNT = 256, CH_CNT_STRIDE = 8;
+__global__ void k_de_gate(const ChParams *__restrict__ q_, int p, unsigned long long target)
+{
+    const ChP q = (ChP)q_;
+    const ChG64 cnt = (ChG64)(q->started + (size_t)p * CH_NCNT * CH_CNT_STRIDE);
+    uint32_t spins = 0;
+    for (;;) {
+        unsigned long long v = 0;
+        for (int i = (int)threadIdx.x; i < CH_NCNT; i += 64) v += __hip_atomic_load(cnt + i * CH_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, sh), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), sh);
+            v += ((unsigned long long)hi << 32) | lo;
+        }
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 23)) { if (threadIdx.x == 0) __hip_atomic_store((ChG)q->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+}
+
+template <int P, class IMG>
+__global__ void __launch_bounds__(CH_NT, 8) k_de_lap(const ChParams *__restrict__ q_, uint32_t ntiles)
+{
+    const ChP q = (ChP)q_;
+    const uint32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t dbg = q->dbg;
+    const int tiles_x = (int)q->tiles_x[P];
+    const int tx = (int)(t % (uint32_t)tiles_x), ty = (int)(t / (uint32_t)tiles_x);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (P < 7 && threadIdx.x == 0 && !(dbg & 8u)) __hip_atomic_fetch_add((ChG64)(q->started + ((size_t)P * CH_NCNT + (t % (uint32_t)CH_NCNT)) * CH_CNT_STRIDE), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P > 0 && !(dbg & 1u)) {
+        if (wv == 0) {
+            constexpr int Q = P > 0 ? P - 1 : 0;
+            constexpr ChDir me = ch_dir<P>(), pr = ch_dir<Q>();
+            constexpr int H = me.hu > pr.hu ? me.hu : pr.hu, R = me.reach_x + pr.reach_x;
+            const int by0 = ty * me.th;
+            const int b0 = max(0, by0 - H) / pr.th, b1 = min((int)q->d.ah - 1, by0 + me.th + H - 1) / pr.th;
+            const int ptx = (int)q->tiles_x[Q];
+            const int txl = max(0, (tx * me.tw - R - pr.tw) / pr.tw), txh = min(ptx - 1, (tx * me.tw + me.tw + R) / pr.tw);
+            const int nx = txh - txl + 1, total = nx > 0 ? (b1 - b0 + 1) * nx : 0;
+            const uint32_t epoch = q->epoch;
+            const ChG flags = (ChG)(q->flags + (size_t)Q * q->maxtiles);
+            const int lane = (int)threadIdx.x;
+            bool ok = true;
+            for (int base = 0; base < total && ok; base += 64) {
+                const int l = base + lane;
+                const bool need = l < total;
+                const int b = b0 + (need ? l / nx : 0), x = txl + (need ? l % nx : 0);
+                const ChG f = flags + (uint32_t)(b * ptx + x);
+                uint32_t spins = 0;
+                for (;;) {
+                    const bool ready = !need || __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                    if (__builtin_amdgcn_ballot_w64(!ready) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load((ChG)q->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
+                }
+            }
+            if (!ok && lane == 0) __hip_atomic_store((ChG)q->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    {
+        float4 *const ps = q->img[P & 1], *const pd = q->img[(P + 1) & 1];
+        if constexpr (std::is_same<IMG, DeImgSc1>::value) {
+            const DeImgSc1 src = {__builtin_amdgcn_make_buffer_rsrc((void *)ps, 0, 0x7fffffff, 0x00020000)};
+            const DeImgSc1 dst = {__builtin_amdgcn_make_buffer_rsrc((void *)pd, 0, 0x7fffffff, 0x00020000)};
+            ch_run<P, DeImgSc1>(q, src, dst, tx, ty, (int)threadIdx.x);
+        } else {
+            const DeImgPlain src = {ps}, dst = {pd};
+            ch_run<P, DeImgPlain>(q, src, dst, tx, ty, (int)threadIdx.x);
+        }
+    }
+    if (P < 7 && !(q->dbg & 2u)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wv == 0 && de_lane_here() == 0) {
+            const ChParams *pq0 = q_;
+            asm volatile("" : "+s"(pq0));
+            const ChP pq = (ChP)pq0;
+            __hip_atomic_store((ChG)(pq->flags + (size_t)P * pq->maxtiles + t), pq->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 struct ChTiles { uint32_t x[8], y[8]; };
 template <int P> void ch_tiles(const fl_dim &d, ChTiles &t)
 {
@@ -257,10 +371,9 @@ size_t de_chain_scratch_bytes(fl_dim d)
 
 // The whole DE: img0 holds the input (in_mode as launch_de_dir's), the result lands in img0 again (eight passes).
 // scratch: de_chain_scratch_bytes() of device memory.  one_by_one: eight launches of the same tiles.
-void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
-                     float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, bool one_by_one)
+static void ch_fill(ChParams &q, ChTiles &tl, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
+                    float dpow, float gspeed, int in_mode, const DeTail *tail)
 {
-    ChParams q = {};
     q.d = d; q.img[0] = img0; q.img[1] = img1;
     for (int i = 0; i < 7; ++i) q.kc.k[i] = coefs7[i];
     for (int m = -9; m <= 9; ++m) {
@@ -274,8 +387,16 @@ void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const
     q.dpow = dpow; q.gspeed = gspeed;
     q.in_mode = in_mode; q.has_tail = tail ? 1 : 0;
     if (tail) q.tail = *tail;
-    ChTiles tl;
     q.maxbands = ch_all_tiles(d, tl);
+    for (int p = 0; p < 8; ++p) { q.tiles_x[p] = tl.x[p]; q.tiles_y[p] = tl.y[p]; }
+}
+
+void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
+                     float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, bool one_by_one)
+{
+    ChParams q = {};
+    ChTiles tl;
+    ch_fill(q, tl, d, img0, img1, coefs7, sstd, cstd, dstd, dpow, gspeed, in_mode, tail);
     // one list per XCD when a stripe of the image is much wider than anything a tile reaches sideways
     uint32_t min_stripe_px = ~0u;
     int max_reach = 0;
@@ -285,7 +406,6 @@ void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const
     }
     q.nstripes = min_stripe_px >= 3u * (uint32_t)max_reach ? 8u : 1u;
     for (int p = 0; p < 8; ++p) {
-        q.tiles_x[p] = tl.x[p]; q.tiles_y[p] = tl.y[p];
         for (uint32_t s_ = 0; s_ <= 8; ++s_) q.x0[p][s_] = s_ >= q.nstripes ? tl.x[p] : (uint32_t)((uint64_t)tl.x[p] * s_ / q.nstripes);
     }
     if (const char *e = getenv("FLAME_DE_CHAIN_ONLY")) {      // timing experiment: only this direction's tiles are in the lists (wrong results)
@@ -310,6 +430,53 @@ void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_de_chain, attr);
     hipLaunchKernelGGL(k_de_chain, dim3(256 * 8), dim3(CH_NT), CH_LDS + 64, st, (const ChParams *)dq);
+}
+
+// ---- overlapped launches -------------------------------------------------------------------------------------------
+static uint32_t lap_maxtiles(fl_dim d)
+{
+    ChTiles t; ch_all_tiles(d, t);
+    uint32_t m = 0;
+    for (int p = 0; p < 8; ++p) m = std::max(m, t.x[p] * t.y[p]);
+    return m;
+}
+// scratch: [0, 1024) parameters | [1056] failure flag (where the persistent launch has it) | [2048, +128 KB) started counts | flags
+static const size_t LAP_STARTED = 2048, LAP_FLAGS = LAP_STARTED + (size_t)8 * CH_NCNT * CH_CNT_STRIDE * sizeof(unsigned long long);
+size_t de_lap_scratch_bytes(fl_dim d) { return LAP_FLAGS + (size_t)8 * lap_maxtiles(d) * sizeof(uint32_t); }
+
+// sa: the lane's stream (directions 0, 2, 4, 6), sb: a second one (1, 3, 5, 7); sb is ordered behind sa's earlier work through
+// `fork`, sa waits for the last direction through `join`.  state: epoch and started-workgroup totals of THIS scratch (all zero
+// after the scratch was allocated and cleared).
+void launch_de_lap(hipStream_t sa, hipStream_t sb, hipEvent_t fork, hipEvent_t join, fl_dim d, float4 *img0, float4 *img1, const float *coefs7,
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, DeLapState *state)
+{
+    ChParams q = {};
+    ChTiles tl;
+    ch_fill(q, tl, d, img0, img1, coefs7, sstd, cstd, dstd, dpow, gspeed, in_mode, tail);
+    q.nstripes = 1;
+    unsigned char *base = static_cast<unsigned char *>(scratch);
+    q.fail = reinterpret_cast<uint32_t *>(base + 1056);
+    q.started = reinterpret_cast<unsigned long long *>(base + LAP_STARTED);
+    q.flags = reinterpret_cast<uint32_t *>(base + LAP_FLAGS);
+    q.maxtiles = lap_maxtiles(d);
+    q.epoch = ++state->epoch;
+    static const uint32_t dbg = getenv("FLAME_DE_LAP_DBG") ? (uint32_t)atoi(getenv("FLAME_DE_LAP_DBG")) : 0u;
+    q.dbg = dbg;
+    if (dbg & 4u) sb = sa;
+    ChParams *dq = static_cast<ChParams *>(scratch);
+    hipLaunchKernelGGL(k_ch_params, dim3(1), dim3(64), 0, sa, dq, q);
+    if (sb != sa) { (void)hipEventRecord(fork, sa); (void)hipStreamWaitEvent(sb, fork, 0); }
+    static unsigned long long attr[8] = {}, attr_pl[8] = {};
+#define LAP(P) do { const uint32_t n = tl.x[P] * tl.y[P]; hipStream_t st_ = (P & 1) ? sb : sa; \
+                    if (P > 0 && sb != sa) hipLaunchKernelGGL(k_de_gate, dim3(1), dim3(64), 0, st_, (const ChParams *)dq, P - 1, state->started[P > 0 ? P - 1 : 0]); \
+                    if (dbg & 16u) { ensure_max_dynamic_lds((const void *)k_de_lap<P, DeImgPlain>, attr_pl[P]); \
+                                     hipLaunchKernelGGL((k_de_lap<P, DeImgPlain>), dim3(n), dim3(CH_NT), DeGeo<P>::LDS, st_, (const ChParams *)dq, n); } \
+                    else { ensure_max_dynamic_lds((const void *)k_de_lap<P, DeImgSc1>, attr[P]); \
+                           hipLaunchKernelGGL((k_de_lap<P, DeImgSc1>), dim3(n), dim3(CH_NT), DeGeo<P>::LDS, st_, (const ChParams *)dq, n); } \
+                    if (P < 7 && !(dbg & 8u)) state->started[P] += n; } while (0)
+    LAP(0); LAP(1); LAP(2); LAP(3); LAP(4); LAP(5); LAP(6); LAP(7);
+#undef LAP
+    if (sb != sa) { (void)hipEventRecord(join, sb); (void)hipStreamWaitEvent(sa, join, 0); }
 }
 
 // 1 when a workgroup of the last persistent launch gave up waiting for a neighbour (a bug; tests look at it)

@@ -70,6 +70,9 @@ struct Lane {
     // the whole eight-direction DE pending as one persistent launch (de_chain.hip): 1 = persistent, 2 = its tiles one direction per launch
     int pend_chain = 0, pend_in_mode = 0;
     void *d_chain = nullptr; size_t chain_bytes = 0;      // the launch's parameter block, list heads and counters
+    // FLAME_DE_CHAIN=4: eight overlapped launches on `stream` and `aux` (idle while the filters run); the scratch's epoch and totals
+    hipEvent_t ev_de_fork = nullptr, ev_de_join = nullptr;
+    DeLapState lap = {};
     float pend_dp[5] = {0, 0, 0, 0, 0}, pend_k7[7] = {0, 0, 0, 0, 0, 0, 0};
     fl_dim pend_dim = {0, 0, 0, 0, 0};
 };
@@ -256,7 +259,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
-    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 0;      // 3: de.hip's kernels, all queued when the tail is known
+    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 0;      // 3: de.hip's kernels, all queued when the tail is known; 4: overlapped launches
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
     c->env_flush_last = env_on("FLAME_FLUSH_LAST");
@@ -329,6 +332,8 @@ void fl_ctx_destroy(fl_ctx *c)
             if (ln.ev_ac[k]) hipEventDestroy(ln.ev_ac[k]);
         }
         if (ln.aux) hipStreamDestroy(ln.aux);
+        if (ln.ev_de_fork) hipEventDestroy(ln.ev_de_fork);
+        if (ln.ev_de_join) hipEventDestroy(ln.ev_de_join);
         if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
         if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
@@ -759,7 +764,10 @@ static void run_de_finish(fl_ctx *c, const float *clip)
                 std::swap(Na, Nb);
             }
             launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], 0, &t);
-        } else
+        } else if (ln.pend_chain == 4)
+            launch_de_lap(ln.stream, ln.aux, ln.ev_de_fork, ln.ev_de_join, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1],
+                          ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, &ln.lap);
+        else
         launch_de_chain(ln.stream, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
                         ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, ln.pend_chain == 2);
         ln.pend_finish = ln.pend_log = ln.pend_last = false;
@@ -819,11 +827,19 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         if (!c->env_de_split && c->env_de_chain && !c->env_de_unfused_ends) {
             // All eight directions in ONE persistent launch (de_chain.hip), deferred as a whole so that a following
             // logscale / colorclip can ride along in the last direction's tiles
-            const size_t need = c->env_de_chain == 3 ? 0 : de_chain_scratch_bytes(d);
+            const size_t need = c->env_de_chain == 3 ? 0 : c->env_de_chain == 4 ? de_lap_scratch_bytes(d) : de_chain_scratch_bytes(d);
             if (L(c).chain_bytes < need) {
                 if (L(c).d_chain) { sync_all(c); (void)hipFree(L(c).d_chain); L(c).d_chain = nullptr; L(c).chain_bytes = 0; }
                 HIPCHK(hipMalloc(&L(c).d_chain, need));
                 L(c).chain_bytes = need;
+                if (c->env_de_chain == 4) {      // flags, started-workgroup totals and the epoch start from zero together
+                    HIPCHK(hipMemsetAsync(L(c).d_chain, 0, need, st));
+                    L(c).lap = DeLapState{};
+                }
+            }
+            if (c->env_de_chain == 4 && !L(c).ev_de_fork) {
+                HIPCHK(hipEventCreateWithFlags(&L(c).ev_de_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&L(c).ev_de_join, hipEventDisableTiming));
             }
             L(c).pend_chain = c->env_de_chain; L(c).pend_in_mode = L(c).pend_yuv ? 2 : 1;
             L(c).pend_yuv = false;

@@ -99,6 +99,11 @@ size_t de_chain_scratch_bytes(fl_dim d);
 void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
                      float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, bool one_by_one);
 int de_chain_failed(const void *scratch);
+// ... and as eight launches on two streams, each starting under the tail of the one before (FLAME_DE_CHAIN=4)
+struct DeLapState { uint32_t epoch; unsigned long long started[8]; };
+size_t de_lap_scratch_bytes(fl_dim d);
+void launch_de_lap(hipStream_t sa, hipStream_t sb, hipEvent_t fork, hipEvent_t join, fl_dim d, float4 *img0, float4 *img1, const float *coefs7,
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, DeLapState *state);
 
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);

@@ -1224,7 +1224,7 @@ def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
     steps = {'yuv': [], 'bilateral': [6.0 * w / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
              'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)]}
     mgrs = {}
-    for mode in ('1', '2', '0'):
+    for mode in ('1', '2', '0', '4'):
         monkeypatch.setenv('FLAME_DE_CHAIN', mode)
         mgrs[mode] = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
     dim = mgrs['1'].fb.calc_dim(w, h)
@@ -1244,12 +1244,41 @@ def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
         for rep in range(4 if w < 1920 else 8):
             per = run(mgrs['1'], chain)
             assert np.array_equal(per.view(np.uint32), one.view(np.uint32)), (chain, rep, int((per != one).sum()))
+            # FLAME_DE_CHAIN=4: the same tiles as eight launches on two streams, each starting under the tail of the one before
+            lap = run(mgrs['4'], chain)
+            assert np.array_equal(lap.view(np.uint32), one.view(np.uint32)), ('overlapped', chain, rep, int((lap != one).sum()))
         std = run(mgrs['0'], chain)
         err = np.abs(std - one)
         assert err.max() <= 2e-5 * max(1.0, float(np.abs(std).max())) and err.mean() < 1e-7 * max(1.0, float(np.abs(std).max())), (chain, err.max(), err.mean())
-    assert lib.fl_debug_de_chain_failed(mgrs['1'].fb.ctx) == 0
+    assert lib.fl_debug_de_chain_failed(mgrs['1'].fb.ctx) == 0 and lib.fl_debug_de_chain_failed(mgrs['4'].fb.ctx) == 0
     for m in mgrs.values():
         m.fb.free()
+
+
+def test_de_overlapped_launches_across_sizes_and_lanes(built, monkeypatch):
+    """FLAME_DE_CHAIN=4 clears nothing between chains (a tile's flag holds the epoch of the chain that finished it, the
+    started-workgroup counts only grow): alternate image sizes and both lanes of one context, every result equal to the
+    same tiles run one direction per launch."""
+    lib = _lib.load()
+    monkeypatch.setenv('FLAME_DE_CHAIN', '4')
+    lap = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
+    monkeypatch.setenv('FLAME_DE_CHAIN', '2')
+    one = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
+    for rep, (w, h) in enumerate([(640, 360), (200, 120), (640, 360), (333, 217), (200, 120), (640, 360)]):
+        dim = lap.fb.calc_dim(w, h)
+        buf = synth_accum(dim, seed=5 + rep)
+        steps = [('yuv', []), ('bilateral', [6.0 * w / 1920., 0.05, 1.5, 0.8, 4.0]), ('logscale', [4.1875, 0.002])]
+        outs = []
+        for m in (lap, one):
+            _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
+            m.fb.write('front', buf)
+            for name, par in steps:
+                arr = np.asarray(par, np.float32)
+                _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
+            outs.append(m.fb.read('front', buf.shape, np.float32))
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (rep, w, h, int((outs[0] != outs[1]).sum()))
+    assert lib.fl_debug_de_chain_failed(lap.fb.ctx) == 0
+    lap.fb.free(); one.fb.free()
 
 
 def test_deferred_filter_fusion_is_bit_identical(mgr):
