@@ -1255,9 +1255,9 @@ def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
         m.fb.free()
 
 
-def test_de_overlapped_launches_across_sizes_and_lanes(built, monkeypatch):
+def test_de_overlapped_launches_across_sizes(built, monkeypatch):
     """FLAME_DE_CHAIN=4 clears nothing between chains (a tile's flag holds the epoch of the chain that finished it, the
-    started-workgroup counts only grow): alternate image sizes and both lanes of one context, every result equal to the
+    started-workgroup counts only grow): alternate image sizes on one context, every result equal to the
     same tiles run one direction per launch."""
     lib = _lib.load()
     monkeypatch.setenv('FLAME_DE_CHAIN', '4')
