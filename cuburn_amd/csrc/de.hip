@@ -138,6 +138,20 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 // Round 4: every direction in 256-thread workgroups, eight to a CU.  The DE alone is 3 % faster than with round 3's mix of
 // 256 and 512 threads, the two-lane frame loop 4.7 % (1.458 -> 1.390 ms at cfg2: smaller workgroups and LDS blocks find room
 // beside the other lane's kernels; profiles/r04_de_shapes_frame.txt).
+// Outputs per thread (experiment, round 4): a tile of TW x TH outputs is worked by TW * TH / OPT threads — the staged region
+// (halo included) is shared by OPT passes of the tap loop, so taller / wider tiles cost no bigger workgroups.
+#ifndef DE_OPT0_
+#define DE_OPT0_ 1     /* the horizontal direction */
+#endif
+#ifndef DE_OPTH_
+#define DE_OPTH_ 1     /* directions 1..3 */
+#endif
+#ifndef DE_OPT_
+#define DE_OPT_ 1      /* directions 4..7 */
+#endif
+#ifndef DE_MINW
+#define DE_MINW 8      /* waves per SIMD the kernels are compiled for (8: 64 registers) */
+#endif
 #ifndef DE_PRIO_STAGE
 #define DE_PRIO_STAGE 3
 #endif
@@ -176,8 +190,10 @@ template <int P> struct DeGeo {
     // output tile
     static constexpr int TW = P == 0 ? DE_TW0_ : (de_hoisted(P) ? DE_TWH_ : (P == 4 || P == 6) ? DE_TWE_ : DE_TW_);
     static constexpr int TH = P == 0 ? DE_TH0_ : (de_hoisted(P) ? DE_THH_ : DE_TH_);
-    static constexpr int NT = TW * TH;                  // threads of a workgroup = output pixels of a tile
+    static constexpr int OPT = P == 0 ? DE_OPT0_ : (de_hoisted(P) ? DE_OPTH_ : DE_OPT_);      // output pixels per thread
+    static constexpr int NT = TW * TH / OPT;            // threads of a workgroup
     static_assert(NT % 64 == 0 && NT <= 1024 && (P == 0 ? TW % 64 == 0 : 64 % TW == 0 && TH % (128 / TW) == 0), "whole waves, rows of equal parity per wave");
+    static_assert((TW * TH) % OPT == 0 && (OPT == 1 || (NT / 64) % 2 == 0), "passes of whole, parity-preserving groups of waves");
     static constexpr bool HOIST = de_hoisted(P);
     // staged region (densities): everything a tile pixel's taps and their blurs can reach
     static constexpr int HU = de_reach(P, true).hu, HV = de_reach(P, true).hv;
@@ -542,7 +558,7 @@ __device__ __forceinline__ void de_tile(const fl_dim &d, const IMG &Nout, const 
 #else
 #define DE_IN_PX(p) de_in_px<IN>(p)
 template <int P, int IN, int OUT>
-__global__ void __launch_bounds__(DeGeo<P>::NT, 8)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
+__global__ void __launch_bounds__(DeGeo<P>::NT, DE_MINW)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
 k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, DeCoefs kc, DeSpatial spk,
          float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
 {
@@ -791,11 +807,14 @@ taps:
     // ---- taps --------------------------------------------------------------------------------
     // (the wave number travels through the tap loop in a scalar register and the lane number is recomputed after it:
     // no vector register is live across the loop — its forms leave none to spare)
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < G::OPT; ++pass) {
+    const int wv = wv0 + pass * (G::NT / 64);                       // the pass's "wave" of output pixels
     float4 res;
     {
         int cu, cv;
-        de_out_px<P>(wv, tid & 63, cu, cv);
+        de_out_px<P>(wv, G::OPT > 1 ? de_lane_here() : (tid & 63), cu, cv);
         // a wave with a dead centre (w_c = 0: the rim of the flame, sparse images) takes the form that handles one
         const bool slow = __builtin_amdgcn_ballot_w64(!(sA[(cu + G::HA) * G::COLS + cv + G::HV].w > 0.0f)) != 0ull;
         if ((G::K & 1) && (wv & 1)) { if (slow) de_tap_loop_slow<P, 1>(sA, sB, wv, cs2, spk, res); else de_tap_loop<P, 1, false>(sA, sB, wv, cs2, spk, res); }
@@ -813,6 +832,7 @@ taps:
             res = p;
         }
         Nout.st((uint32_t)(yo * (int)d.astride + xo), res);
+    }
     }
     DE_PHASE(4);
 }
@@ -863,7 +883,7 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
                               float cs2, float ads, float dpow, float gspeed, DeTail tail)
 {
     using G = DeGeo<P>;
-    static_assert(G::LDS * (2048 / G::NT) <= 160 * 1024, "LDS must allow 32 waves per CU");
+    static_assert(G::LDS * (DE_MINW * 256 / G::NT) <= 160 * 1024, "LDS must allow DE_MINW waves per SIMD");
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;

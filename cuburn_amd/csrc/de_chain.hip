@@ -31,6 +31,23 @@
 // again).  The overlapped launches at the end of this file get the same overlap between directions from the hardware's own
 // in-order dispatch.
 #define DE_CHAIN_BUILD 1
+// (the tile shapes of this file are its own, whatever an experiment build of de.hip is given on the command line)
+#undef DE_TW_
+#undef DE_TWE_
+#undef DE_TH_
+#undef DE_TWH_
+#undef DE_THH_
+#undef DE_TW0_
+#undef DE_TH0_
+#undef DE_LANE_GROUPS
+#undef DE_OPT0_
+#undef DE_OPTH_
+#undef DE_OPT_
+#undef DE_MINW
+#define DE_OPT0_ 1
+#define DE_OPTH_ 1
+#define DE_OPT_ 1
+#define DE_MINW 8
 #define DE_TW_ 8        /* directions 4..7: 32 x 8 */
 #define DE_TWE_ 8
 #define DE_TH_ 32
