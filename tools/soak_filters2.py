@@ -33,7 +33,8 @@ def report(tag, k, dev, ref, vals, rel=2e-3, ab=2e-4):
     print('%s %s case %2d: violations %.2e max %.2e nonfinite-on-device %d  vals=%s' % (flag, tag, k, viol, err.max() if err.size else 0, bad_fin, np.round(vals, 4)), flush=True)
 
 
-for k in range(cases):
+only = [int(v) for v in os.environ['SOAK_ONLY'].split(',')] if os.environ.get('SOAK_ONLY') else None
+for k in (only or range(cases)):
     rs = np.random.RandomState(9000 + k)
     w, h = int(rs.choice([161, 320, 480])), int(rs.choice([97, 180, 270]))
     dim = m.fb.set_dim(w, h); d = O.calc_dim(w, h)
