@@ -108,6 +108,26 @@ __host__ __device__ constexpr int de_dv(int P, int par, int dx, int dy)
     return dx - (de_shear(P, par + dy) - de_shear(P, par));
 }
 __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // integer steps: H+ / H- planes
+// Phase planes: the distinct (next - here, prev - here, sign of r) combinations of a direction's taps r = -15 .. 15, r != 0
+struct DeHCombos { int n; int ndx[8], ndy[8], pdx[8], pdy[8], sg[8]; int of_r[31]; };
+__host__ __device__ constexpr DeHCombos de_hcombos(int P)
+{
+    DeHCombos c = {};
+    for (int r = -15; r <= 15; ++r) {
+        if (r == 0) { c.of_r[r + 15] = 0; continue; }
+        const int ndx = de_dx(P, r + 1) - de_dx(P, r), ndy = de_dy(P, r + 1) - de_dy(P, r);
+        const int pdx = de_dx(P, r - 1) - de_dx(P, r), pdy = de_dy(P, r - 1) - de_dy(P, r);
+        const int sg = r < 0 ? -1 : 1;
+        int k = 0;
+        for (; k < c.n; ++k) if (c.ndx[k] == ndx && c.ndy[k] == ndy && c.pdx[k] == pdx && c.pdy[k] == pdy && c.sg[k] == sg) break;
+        if (k == c.n) {
+            if (c.n == 8) { c.n = 99; return c; }
+            c.ndx[k] = ndx; c.ndy[k] = ndy; c.pdx[k] = pdx; c.pdy[k] = pdy; c.sg[k] = sg; ++c.n;
+        }
+        c.of_r[r + 15] = k;
+    }
+    return c;
+}
 
 // Tile shapes (output pixels = threads of a workgroup).  Round 2 used 32 x 32 (8 x 128 for the horizontal
 // direction): two 1024-thread workgroups per CU.  A workgroup alternates a staging phase that mostly WAITS
@@ -151,6 +171,16 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 #endif
 #ifndef DE_MINW
 #define DE_MINW 8      /* waves per SIMD the kernels are compiled for (8: 64 registers) */
+#endif
+// Phase planes for the half-slope directions (experiment, round 4; the verdicts' "r mod 4" planes): the gradient factor
+// exp2(+-gspeed * (next.w - prev.w) / (avg + 1e-6)) of a tap depends on the tap position, the sign of r and — the tap offsets being
+// rounded — on r mod 4: eight values per staged pixel, computed when plane B is (32 bytes per pixel more LDS), instead of one
+// v_exp_f32 + a subtraction + a product per tap.  Same operands in the same order: bit-identical results.
+#ifndef DE_HPLANES
+#define DE_HPLANES 0
+#endif
+#ifndef DE_MINW_H
+#define DE_MINW_H 4    /* waves per SIMD of the half-slope kernels with phase planes (LDS allows four workgroups per CU) */
 #endif
 #ifndef DE_PRIO_STAGE
 #define DE_PRIO_STAGE 3
@@ -219,7 +249,11 @@ template <int P> struct DeGeo {
     static constexpr int NITB = ROWWISE ? (BROWS + RSB - 1) / RSB : (NPXB + NT - 1) / NT;
     // LDS: A float4[NPXA] | B float4[NPXB] | (integer-step directions) the fast path's density plane float[NPX];
     // the nested preparation's two dense float planes live in B's space
-    static constexpr size_t LDS = (size_t)(NPXA + NPXB) * 16 + (de_hoisted(P) ? (size_t)NPX * 4 : 0) + 64;
+    static constexpr bool HPL = DE_HPLANES && !de_hoisted(P);      // phase planes: float[8][NPXB] behind plane B
+    static constexpr DeHCombos HC = de_hcombos(P);
+    static_assert(!HPL || HC.n <= 8, "at most eight gradient phases");
+    static constexpr int MINW = HPL ? DE_MINW_H : DE_MINW;
+    static constexpr size_t LDS = (size_t)(NPXA + NPXB) * 16 + (de_hoisted(P) ? (size_t)NPX * 4 : 0) + (HPL ? (size_t)NPXB * 32 : 0) + 64;
     static constexpr int SPAN = de_shear(P, TH - 1) < 0 ? -de_shear(P, TH - 1) : de_shear(P, TH - 1);
     // element offset of image displacement (dx, dy) from a position in a row of parity par
     static constexpr int off(int par, int dx, int dy) { return dy * COLS + de_dv(P, par, dx, dy); }
@@ -321,7 +355,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 //   x = |ds| * w_q^dpow,  y = 1 if w_q > 0 else 0,
 //   z, w = cs*|n_q|^2 + Kp - H+(q),  cs*|n_q|^2 + Kp - H-(q)      (integer-step directions: the hoisted gradient terms)
 //   z, w = cs*|n_q|^2 + Kp,          gspeed / (avg(q) + 1e-6)     (half-slope directions: the gradient term stays in the loop)
-struct DeTap { f4v a, b; };
+struct DeTap { f4v a, b; float h; };
 
 #ifdef DE_X_NOLDS      /* timing build: the tap loop without its LDS reads (results are garbage) */
 #define DE_RD128(dst, addr, boff) asm volatile("; no read %1 %2" : "=v"(dst) : "v"(addr), "n"(boff) : "memory")
@@ -332,7 +366,9 @@ struct DeTap { f4v a, b; };
 template <int P> __host__ __device__ constexpr int de_tap_reads(int r)       // LDS reads issued for tap r
 {
     if (r > 15) return 0;
-    return ((r < 15 || !de_hoisted(P)) ? 1 : 0) + (r != 0 ? 1 : 0);          // A of tap r+1; B of tap r (the centre's own terms are in registers)
+    constexpr bool hpl = DE_HPLANES && !de_hoisted(P);
+    return ((r < 15 || (!de_hoisted(P) && !hpl)) ? 1 : 0) + (r != 0 ? 1 : 0) + (hpl && r != 0 ? 1 : 0);          // A of tap r+1; B of tap r (the centre's own terms are in registers); phase plane
+
 }
 
 // SLOW = false: every centre of the wave is live (w_c > 0) — all but the rim of a flame.  Then the exponent of a pair is
@@ -362,6 +398,7 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     const float4 *__restrict__ bB = sB + (cb + MINOFFB);
     // LDS byte addresses of the two planes' bases (dynamic LDS starts at the kernel's LDS base)
     uint32_t aA = (uint32_t)(size_t)bA, aB = (uint32_t)(size_t)bB;
+    uint32_t aH = (uint32_t)(size_t)(reinterpret_cast<const float *>(sB + G::NPXB) + (cb + MINOFFB));      // phase planes (HPL): float[8][NPXB]
     const float4 cen = bA[TOFF(0)];
     // the reference normalises the centre with 1/(w + 1e-6) and the taps with 1/w
     const float cfix = cen.w * frcp(cen.w + 1.0e-6f);
@@ -379,7 +416,7 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     // the centre's own pair (r = 0): its plane terms from registers (no gradient term, no density difference)
     const float y0c = fmaf(cs2, fmaf(cen.z, cen.z, fmaf(cen.y, cen.y, cen.x * cen.x)), Kp) + Dl;
     float cds = bB[TOFFB(0)].x;                               // |ds| * w_c^dpow
-    float wprev = G::HOIST ? 0.0f : bA[TOFF(-16)].w;
+    float wprev = (G::HOIST || G::HPL) ? 0.0f : bA[TOFF(-16)].w;
     const float4 p0 = bA[TOFF(-15)];
     f4v pix = {p0.x, p0.y, p0.z, p0.w};
     f2v oxy = {0.0f, 0.0f}, ozw = {0.0f, 0.0f};               // (sum f*w*nx, sum f*w*ny), (sum f*w*nz, sum f*w)
@@ -393,8 +430,9 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
         constexpr int g = decltype(gc)::value;
 #define ISSUE_TAP(k) if constexpr (-15 + g * 2 + (k) <= 15) { \
             constexpr int r = -15 + g * 2 + (k); \
-            if constexpr (r < 15 || !G::HOIST) DE_RD128(L[g % NBUF][k].a, aA, TOFF(r + 1) * 16); \
-            if constexpr (r != 0) DE_RD128(L[g % NBUF][k].b, aB, TOFFB(r) * 16); }
+            if constexpr (r < 15 || (!G::HOIST && !G::HPL)) DE_RD128(L[g % NBUF][k].a, aA, TOFF(r + 1) * 16); \
+            if constexpr (r != 0) DE_RD128(L[g % NBUF][k].b, aB, TOFFB(r) * 16); \
+            if constexpr (G::HPL && r != 0) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(L[g % NBUF][k].h) : "v"(aH), "n"((TOFFB(r) + G::HC.of_r[r + 15] * G::NPXB) * 4) : "memory"); }
         ISSUE_TAP(0) ISSUE_TAP(1)
 #undef ISSUE_TAP
     };
@@ -404,18 +442,13 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
         else if constexpr (g + 1 < 16) issue(std::integral_constant<int, g + 1>{});
         constexpr int inflight = (!SLOW && g + 1 < 16) ? de_tap_reads<P>(-15 + (g + 1) * 2) + de_tap_reads<P>(-14 + (g + 1) * 2) : 0;
         DeTap (&T)[2] = L[g % NBUF];
-        if constexpr (SLOW)
-            asm volatile("s_waitcnt lgkmcnt(%[n])"
-                         : "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b),
-                           "+v"(aA), "+v"(aB), "+v"(oxy), "+v"(ozw), "+v"(wsum),
-                           "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(Dl), "+v"(cds), "+v"(dcs)
-                         : [n] "n"(inflight));
-        else
-            asm volatile("s_waitcnt lgkmcnt(%[n])"
-                         : "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b),
-                           "+v"(aA), "+v"(aB), "+v"(oxy), "+v"(ozw), "+v"(wsum),
-                           "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(Dl), "+v"(cds)
-                         : [n] "n"(inflight));
+#define DE_WAIT_OPS "+v"(T[0].a), "+v"(T[0].b), "+v"(T[1].a), "+v"(T[1].b), "+v"(aA), "+v"(aB), "+v"(oxy), "+v"(ozw), "+v"(wsum), \
+                    "+v"(pix), "+v"(wprev), "+v"(Cx), "+v"(Cy), "+v"(Cz), "+v"(Dl), "+v"(cds)
+        if constexpr (SLOW && G::HPL) asm volatile("s_waitcnt lgkmcnt(%[n])" : DE_WAIT_OPS, "+v"(dcs), "+v"(T[0].h), "+v"(T[1].h), "+v"(aH) : [n] "n"(inflight));
+        else if constexpr (SLOW) asm volatile("s_waitcnt lgkmcnt(%[n])" : DE_WAIT_OPS, "+v"(dcs) : [n] "n"(inflight));
+        else if constexpr (G::HPL) asm volatile("s_waitcnt lgkmcnt(%[n])" : DE_WAIT_OPS, "+v"(T[0].h), "+v"(T[1].h), "+v"(aH) : [n] "n"(inflight));
+        else asm volatile("s_waitcnt lgkmcnt(%[n])" : DE_WAIT_OPS : [n] "n"(inflight));
+#undef DE_WAIT_OPS
         // The two taps of a step go through the arithmetic in LOCKSTEP, stage by stage: a tap is a chain of ~10 dependent
         // instructions, and a wave that issues dependent instructions back to back gets one issue slot per ~10 clocks
         // (tools/valu_bench.hip: 1.56 ns per wave-instruction per SIMD for a dependent chain against 1.05-1.23 for
@@ -444,7 +477,10 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
         if constexpr (r0 != 0) { const float d0 = cds - b0.x; e0 = t0 - fabsf(d0); }
         if constexpr (two && r1 != 0) { const float d1 = cds - b1.x; e1 = t1 - fabsf(d1); }
         // gradient term of the half-slope directions: next.w - prev.w around the tap, b.w = gspeed / (avg + 1e-6)
-        if constexpr (!G::HOIST) {
+        if constexpr (G::HPL) {
+            if constexpr (r0 != 0) e0 -= T[0].h;
+            if constexpr (two && r1 != 0) e1 -= T[1].h;
+        } else if constexpr (!G::HOIST) {
             float g0 = 0.0f, g1 = 0.0f;
             if constexpr (r0 != 0) g0 = (T[0].a.w - wprev) * b0.w;
             if constexpr (two && r1 != 0) g1 = (T[1].a.w - px0.w) * b1.w;
@@ -462,7 +498,7 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
             wsum += f1;
             oxy.x = fmaf(fw1, px1.x, oxy.x); oxy.y = fmaf(fw1, px1.y, oxy.y); ozw.x = fmaf(fw1, px1.z, ozw.x); ozw.y += fw1;
             wprev = px1.w;
-            if (r1 < 15 || !G::HOIST) pix = T[1].a;
+            if (r1 < 15 || (!G::HOIST && !G::HPL)) pix = T[1].a;
         }
     };
     if constexpr (!SLOW) issue(std::integral_constant<int, 0>{});
@@ -558,7 +594,7 @@ __device__ __forceinline__ void de_tile(const fl_dim &d, const IMG &Nout, const 
 #else
 #define DE_IN_PX(p) de_in_px<IN>(p)
 template <int P, int IN, int OUT>
-__global__ void __launch_bounds__(DeGeo<P>::NT, DE_MINW)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
+__global__ void __launch_bounds__(DeGeo<P>::NT, DeGeo<P>::MINW)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
 k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, DeCoefs kc, DeSpatial spk,
          float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
 {
@@ -780,6 +816,18 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
         } else {
             pb[it].z = yk;
             pb[it].w = ra;
+            if constexpr (G::HPL) {
+                // the in-loop form's operands in its order: (A.w at tap r + 1 - A.w at tap r - 1) * ra, then exp2 of +- that
+                float *sH = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16) + bidx;      // float[8][NPXB]: lanes read consecutive words
+#pragma unroll
+                for (int c = 0; c < G::HC.n; ++c) {
+                    const int on0 = G::off(0, G::HC.ndx[c], G::HC.ndy[c]), on1 = G::off(1, G::HC.ndx[c], G::HC.ndy[c]);
+                    const int op0 = G::off(0, G::HC.pdx[c], G::HC.pdy[c]), op1 = G::off(1, G::HC.pdx[c], G::HC.pdy[c]);
+                    const int on = (G::K & 1) ? (par ? on1 : on0) : on0, op = (G::K & 1) ? (par ? op1 : op0) : op0;
+                    const float gq = (sW[idx + on] - sW[idx + op]) * ra;
+                    sH[c * G::NPXB] = fexp2(G::HC.sg[c] < 0 ? -gq : gq);
+                }
+            }
         }
     }
     }
@@ -883,7 +931,7 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
                               float cs2, float ads, float dpow, float gspeed, DeTail tail)
 {
     using G = DeGeo<P>;
-    static_assert(G::LDS * (DE_MINW * 256 / G::NT) <= 160 * 1024, "LDS must allow DE_MINW waves per SIMD");
+    static_assert(G::LDS * (G::MINW * 256 / G::NT) <= 160 * 1024, "LDS must allow MINW waves per SIMD");
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;

@@ -44,6 +44,8 @@
 #undef DE_OPTH_
 #undef DE_OPT_
 #undef DE_MINW
+#undef DE_HPLANES
+#define DE_HPLANES 0
 #define DE_OPT0_ 1
 #define DE_OPTH_ 1
 #define DE_OPT_ 1
