@@ -13,7 +13,35 @@
 #define VP(i) (v[(i)])
 #define OUT(a, b) do { ox += (a); oy += (b); } while (0)
 
+// atan2(a, b) in ~24 instructions (the device library's atan2f is 38: it divides through frexp / ldexp so that the quotient
+// survives operands near the ends of the float range, and sorts out zeros and infinities one compare at a time; the reference's is
+// CUDA's library function under -use_fast_math, 2-3 ulp).  min / max -> one hardware reciprocal -> atan(q) = q + q^3 P(q^2) on [0, 1]
+// (own least-squares minimax fit, degree 6 in q^2: 1.2e-7 absolute, 2.9e-7 relative in float arithmetic) -> octant fix-ups.
+// atan2(0, 0) = 0; NaN in, NaN out; both operands infinite gives NaN (such a point is discarded by the caller either way).
+#ifndef FL_LIBM_ATAN2
+__device__ __forceinline__ float v_atan2(float a, float b)
+{
+    const float ax = fabsf(b), ay = fabsf(a);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.17549435e-38f), mn = fminf(ax, ay);
+    const float q = mn * frcp(mx), s = q * q;
+    float p = fmaf(s, -0.004355378448963165f, 0.023040037602186203f);
+    p = fmaf(s, p, -0.05777344852685928f);
+    p = fmaf(s, p, 0.09794224053621292f);
+    p = fmaf(s, p, -0.13976578414440155f);
+    p = fmaf(s, p, 0.19962702691555023f);
+    p = fmaf(s, p, -0.3333165943622589f);
+    float r = fmaf(q * s, p, q);
+    r = ay > ax ? FM_PI_2 - r : r;
+    r = b < 0.0f ? FM_PI - r : r;
+    r = (a != a || b != b) ? __builtin_nanf("") : r;
+    return copysignf(r, a);
+}
+#else
 __device__ __forceinline__ float v_atan2(float a, float b) { return atan2f(a, b); }
+#endif
+// fmodf(a, pi) for a > 0 of a few pi (bipolar's wrap of an angle that left [-pi/2, pi/2]): a - pi floor(a / pi), 4 instructions where
+// the device library's exact fmodf is a ~60-instruction loop that every lane of the wave sits through once one lane needs it
+__device__ __forceinline__ float v_fmod_pi(float a) { return fmaf(-FM_PI, floorf(a * 0.318309886183791f), a); }
 // box-muller style radius used by gaussian_blur / radial_blur (variations.py:318-323)
 __device__ __forceinline__ float v_gauss_r(float w, mwc_t &r) {
     return w * 0.57736f * fsqrt(fdiv(-2.0f * flog2(mwc_next_01(r)), FM_LOG2E));
@@ -179,8 +207,8 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
                OUT(VW * nx * tx, VW * ny * ty); } break;
     case 55: { float t = r2 + 1.0f, x2 = tx * 2.0f, ps = -FM_PI_2 * VP(0);             // bipolar: shift
                float y = 0.5f * v_atan2(2.0f * ty, r2 - 1.0f) + ps;
-               if (y > FM_PI_2) y = -FM_PI_2 + fmodf(y + FM_PI_2, FM_PI);
-               else if (y < -FM_PI_2) y = FM_PI_2 - fmodf(FM_PI_2 - y, FM_PI);
+               if (y > FM_PI_2) y = -FM_PI_2 + v_fmod_pi(y + FM_PI_2);
+               else if (y < -FM_PI_2) y = FM_PI_2 - v_fmod_pi(FM_PI_2 - y);
                OUT(VW * 0.25f * FM_2_PI * flog(fdiv(t + x2, t - x2)), VW * FM_2_PI * y); } break;
     case 56: { float rx = rintf(tx), ry = rintf(ty), fx = tx - rx, fy = ty - ry;       // boarders
                if (mwc_next_01(r) > 0.75f) {
