@@ -1257,8 +1257,8 @@ def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
 
 def test_de_overlapped_launches_across_sizes(built, monkeypatch):
     """FLAME_DE_CHAIN=4 clears nothing between chains (a tile's flag holds the epoch of the chain that finished it, the
-    started-workgroup counts only grow): alternate image sizes on one context, every result equal to the
-    same tiles run one direction per launch."""
+    started-workgroup counts only grow): alternate image sizes on one context, then frames in flight on both stream lanes,
+    every result equal to the same tiles run one direction per launch."""
     lib = _lib.load()
     monkeypatch.setenv('FLAME_DE_CHAIN', '4')
     lap = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
@@ -1277,6 +1277,24 @@ def test_de_overlapped_launches_across_sizes(built, monkeypatch):
                 _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
             outs.append(m.fb.read('front', buf.shape, np.float32))
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (rep, w, h, int((outs[0] != outs[1]).sum()))
+    assert lib.fl_debug_de_chain_failed(lap.fb.ctx) == 0
+    # ... and through queue_frame: six frames, two in flight, alternating between the stream lanes (each lane has its own scratch, gates on its own
+    # second stream), same seeds -> the same pixels as the one-direction-per-launch form
+    gnm, prof = small(configs.cfg3, 640, 360, samples=2 ** 24)
+    gprof = profile.wrap(prof, gnm)
+    frames = {}
+    for name, m in (('lap', lap), ('one', one)):
+        rdr = render.Renderer(gnm, gprof)
+        frames[name] = []
+        prev = None
+        for k in range(7):                                   # frame k is queued before frame k - 1 is waited for
+            cur = m.queue_frame(rdr, gnm, gprof, 0.1 + 0.15 * k) if k < 6 else None
+            if prev is not None:
+                prev[0].synchronize()
+                frames[name].append(np.array(prev[1]))
+            prev = cur
+    for k in range(6):
+        assert np.array_equal(frames['lap'][k], frames['one'][k]), (k, int((frames['lap'][k] != frames['one'][k]).sum()))
     assert lib.fl_debug_de_chain_failed(lap.fb.ctx) == 0
     lap.fb.free(); one.fb.free()
 
