@@ -39,6 +39,29 @@ __device__ __forceinline__ float v_atan2(float a, float b)
 #else
 __device__ __forceinline__ float v_atan2(float a, float b) { return atan2f(a, b); }
 #endif
+// sinh / cosh in 5-16 instructions (the device library's are 120 and 116 — an extended-precision exponential each; the reference's are
+// CUDA's library functions over ex2.approx under -use_fast_math).  h = e^|x| / 2 from ONE v_exp_f32 (the halving in the exponent, so that
+// nothing overflows before the result does), cosh = h + 1/(4h), sinh = h - 1/(4h); below |x| = 0.5, where that difference cancels, the
+// odd series to x^9 / 9! (next term 1.2e-11 relative).  The thirteen trigonometric / hyperbolic variations (sin .. coth) call both.
+#ifndef FL_LIBM_ATAN2
+__device__ __forceinline__ float v_cosh(float x)
+{
+    const float h = fexp2(fmaf(fabsf(x), FM_LOG2E, -1.0f));
+    return fmaf(0.25f, frcp(h), h);
+}
+__device__ __forceinline__ float v_sinh(float x)
+{
+    const float ax = fabsf(x), h = fexp2(fmaf(ax, FM_LOG2E, -1.0f));
+    const float big = fmaf(-0.25f, frcp(h), h), x2 = x * x;
+    float p = fmaf(x2, 2.7557319e-6f, 1.9841270e-4f);
+    p = fmaf(x2, p, 8.3333333e-3f);
+    p = fmaf(x2, p, 1.6666667e-1f);
+    return ax < 0.5f ? fmaf(x * x2, p, x) : copysignf(big, x);
+}
+#else
+__device__ __forceinline__ float v_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ float v_sinh(float x) { return sinhf(x); }
+#endif
 // fmodf(a, pi) for a > 0 of a few pi (bipolar's wrap of an angle that left [-pi/2, pi/2]): a - pi floor(a / pi), 4 instructions where
 // the device library's exact fmodf is a ~60-instruction loop that every lane of the wave sits through once one lane needs it
 __device__ __forceinline__ float v_fmod_pi(float a) { return fmaf(-FM_PI, floorf(a * 0.318309886183791f), a); }
@@ -100,7 +123,7 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
     case 19: { float a = v_atan2(tx, ty), sa = fsin(a), rr = VW * fpow(fsqrt(r2), sa); // power
                OUT(rr * fcos(a), rr * sa); } break;
     case 20: { float a = FM_PI * tx;                                                   // cosine
-               OUT(VW * fcos(a) * coshf(ty), -VW * fsin(a) * sinhf(ty)); } break;
+               OUT(VW * fcos(a) * v_cosh(ty), -VW * fsin(a) * v_sinh(ty)); } break;
     case 21: { float dx = xf[2]; dx *= dx;                                             // rings
                float rr = fsqrt(r2), a = v_atan2(tx, ty);
                rr = VW * (fmodf(rr + dx, 2.0f * dx) - dx + rr * (1.0f - dx));
@@ -241,7 +264,7 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
                float a1 = flog(xmax + fsqrt(xmax - 1.0f)), a2 = -acosf(fdiv(tx, xmax)), nw = fdiv(VW, 11.57034632f);
                float snv = fsin(a1), csv = fcos(a1);
                if (ty > 0.0f) snv = -snv;
-               OUT(nw * coshf(a2) * csv, nw * sinhf(a2) * snv); } break;
+               OUT(nw * v_cosh(a2) * csv, nw * v_sinh(a2) * snv); } break;
     case 62: { float tmp = r2 + 1.0f, x2 = 2.0f * tx;                                  // elliptic
                float xmax = 0.5f * (fsqrt(tmp + x2) + fsqrt(tmp - x2));
                float a = fdiv(tx, xmax), b = 1.0f - a * a, ssx = xmax - 1.0f, nw = fdiv(VW, FM_PI_2);
@@ -303,26 +326,26 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
     case 81: OUT(VW * (tx + VP(2) * fsin(ty * VP(0))), VW * (ty + VP(3) * fsin(tx * VP(1)))); break;   // waves2: freqx freqy scalex scaley
     case 82: { float e = fexp(tx); OUT(VW * e * fcos(ty), VW * e * fsin(ty)); } break;  // exp
     case 83: OUT(VW * 0.5f * flog(r2), VW * v_atan2(ty, tx)); break;                   // log
-    case 84: OUT(VW * fsin(tx) * coshf(ty), VW * fcos(tx) * sinhf(ty)); break;         // sin
-    case 85: OUT(VW * fcos(tx) * coshf(ty), -VW * fsin(tx) * sinhf(ty)); break;        // cos
-    case 86: { float d = frcp(fcos(2.0f * tx) + coshf(2.0f * ty));                     // tan
-               OUT(VW * d * fsin(2.0f * tx), VW * d * sinhf(2.0f * ty)); } break;
-    case 87: { float d = fdiv(2.0f, fcos(2.0f * tx) + coshf(2.0f * ty));               // sec
-               OUT(VW * d * fcos(tx) * coshf(ty), VW * d * fsin(tx) * sinhf(ty)); } break;
-    case 88: { float d = fdiv(2.0f, coshf(2.0f * ty) - fcos(2.0f * tx));               // csc
-               OUT(VW * d * fsin(tx) * coshf(ty), -VW * d * fcos(tx) * sinhf(ty)); } break;
-    case 89: { float d = frcp(coshf(2.0f * ty) - fcos(2.0f * tx));                     // cot
-               OUT(VW * d * fsin(2.0f * tx), -VW * d * sinhf(2.0f * ty)); } break;
-    case 90: OUT(VW * sinhf(tx) * fcos(ty), VW * coshf(tx) * fsin(ty)); break;         // sinh
-    case 91: OUT(VW * coshf(tx) * fcos(ty), VW * sinhf(tx) * fsin(ty)); break;         // cosh
-    case 92: { float d = frcp(fcos(2.0f * ty) + coshf(2.0f * tx));                     // tanh
-               OUT(VW * d * sinhf(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
-    case 93: { float d = fdiv(2.0f, fcos(2.0f * ty) + coshf(2.0f * tx));               // sech
-               OUT(VW * d * fcos(ty) * coshf(tx), -VW * d * fsin(ty) * sinhf(tx)); } break;
-    case 94: { float d = fdiv(2.0f, coshf(2.0f * tx) - fcos(2.0f * ty));               // csch
-               OUT(VW * d * sinhf(tx) * fcos(ty), -VW * d * coshf(tx) * fsin(ty)); } break;
-    case 95: { float d = frcp(coshf(2.0f * tx) - fcos(2.0f * ty));                     // coth
-               OUT(VW * d * sinhf(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
+    case 84: OUT(VW * fsin(tx) * v_cosh(ty), VW * fcos(tx) * v_sinh(ty)); break;         // sin
+    case 85: OUT(VW * fcos(tx) * v_cosh(ty), -VW * fsin(tx) * v_sinh(ty)); break;        // cos
+    case 86: { float d = frcp(fcos(2.0f * tx) + v_cosh(2.0f * ty));                     // tan
+               OUT(VW * d * fsin(2.0f * tx), VW * d * v_sinh(2.0f * ty)); } break;
+    case 87: { float d = fdiv(2.0f, fcos(2.0f * tx) + v_cosh(2.0f * ty));               // sec
+               OUT(VW * d * fcos(tx) * v_cosh(ty), VW * d * fsin(tx) * v_sinh(ty)); } break;
+    case 88: { float d = fdiv(2.0f, v_cosh(2.0f * ty) - fcos(2.0f * tx));               // csc
+               OUT(VW * d * fsin(tx) * v_cosh(ty), -VW * d * fcos(tx) * v_sinh(ty)); } break;
+    case 89: { float d = frcp(v_cosh(2.0f * ty) - fcos(2.0f * tx));                     // cot
+               OUT(VW * d * fsin(2.0f * tx), -VW * d * v_sinh(2.0f * ty)); } break;
+    case 90: OUT(VW * v_sinh(tx) * fcos(ty), VW * v_cosh(tx) * fsin(ty)); break;         // sinh
+    case 91: OUT(VW * v_cosh(tx) * fcos(ty), VW * v_sinh(tx) * fsin(ty)); break;         // cosh
+    case 92: { float d = frcp(fcos(2.0f * ty) + v_cosh(2.0f * tx));                     // tanh
+               OUT(VW * d * v_sinh(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
+    case 93: { float d = fdiv(2.0f, fcos(2.0f * ty) + v_cosh(2.0f * tx));               // sech
+               OUT(VW * d * fcos(ty) * v_cosh(tx), -VW * d * fsin(ty) * v_sinh(tx)); } break;
+    case 94: { float d = fdiv(2.0f, v_cosh(2.0f * tx) - fcos(2.0f * ty));               // csch
+               OUT(VW * d * v_sinh(tx) * fcos(ty), -VW * d * v_cosh(tx) * fsin(ty)); } break;
+    case 95: { float d = frcp(v_cosh(2.0f * tx) - fcos(2.0f * ty));                     // coth
+               OUT(VW * d * v_sinh(2.0f * tx), VW * d * fsin(2.0f * ty)); } break;
     case 97: { float xpw = tx + VW, xmw = tx - VW, y2 = ty * ty;                       // flux: spread
                float ar = VW * (2.0f + VP(0)) * fsqrt(fdiv(fsqrt(y2 + xpw * xpw), fsqrt(y2 + xmw * xmw)));
                float aa = (v_atan2(ty, xmw) - v_atan2(ty, xpw)) * 0.5f;
