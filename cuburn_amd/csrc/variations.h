@@ -62,6 +62,24 @@ __device__ __forceinline__ float v_sinh(float x)
 __device__ __forceinline__ float v_cosh(float x) { return coshf(x); }
 __device__ __forceinline__ float v_sinh(float x) { return sinhf(x); }
 #endif
+// fmodf(a, b) in 13 instructions where the quotient fits a float's integers (|a / b| < 2^21): q = trunc(a / b) from the hardware reciprocal,
+// r = a - q b in one fma, then the two ways q can be off by one put right (|r| >= |b|: q too small; r on the wrong side of 0: q too
+// big) — the result has the sign of a, magnitude below |b|, and differs from the exact remainder by the fma's rounding only.
+// Larger quotients (and b = 0, NaN) take the device library's exact loop, 45 instructions + 1-2 rounds, which every call paid before.
+#ifndef FL_LIBM_ATAN2
+__device__ __forceinline__ float v_fmod(float a, float b)
+{
+    const float qf = a * frcp(b);
+    if (!(fabsf(qf) < 2097152.0f)) return fmodf(a, b);      // (the quotient from v_rcp_f32 is good to ~2 ulp: off by one at most)
+    float r = fmaf(-truncf(qf), b, a);
+    const float sb = copysignf(b, a);                       // |b| with a's sign
+    r = fabsf(r) >= fabsf(b) ? r - sb : r;
+    r = (r != 0.0f && (r < 0.0f) != (a < 0.0f)) ? r + sb : r;
+    return copysignf(r, a);
+}
+#else
+__device__ __forceinline__ float v_fmod(float a, float b) { return fmodf(a, b); }
+#endif
 // fmodf(a, pi) for a > 0 of a few pi (bipolar's wrap of an angle that left [-pi/2, pi/2]): a - pi floor(a / pi), 4 instructions where
 // the device library's exact fmodf is a ~60-instruction loop that every lane of the wave sits through once one lane needs it
 __device__ __forceinline__ float v_fmod_pi(float a) { return fmaf(-FM_PI, floorf(a * 0.318309886183791f), a); }
@@ -126,11 +144,11 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
                OUT(VW * fcos(a) * v_cosh(ty), -VW * fsin(a) * v_sinh(ty)); } break;
     case 21: { float dx = xf[2]; dx *= dx;                                             // rings
                float rr = fsqrt(r2), a = v_atan2(tx, ty);
-               rr = VW * (fmodf(rr + dx, 2.0f * dx) - dx + rr * (1.0f - dx));
+               rr = VW * (v_fmod(rr + dx, 2.0f * dx) - dx + rr * (1.0f - dx));
                OUT(rr * fcos(a), rr * fsin(a)); } break;
     case 22: { float dx = xf[2]; dx *= dx * FM_PI;                                     // fan
                float dx2 = 0.5f * dx, dy = xf[5], a = v_atan2(tx, ty);
-               a += (fmodf(a + dy, dx) > dx2) ? -dx2 : dx2;
+               a += (v_fmod(a + dy, dx) > dx2) ? -dx2 : dx2;
                float rr = VW * fsqrt(r2);
                OUT(rr * fcos(a), rr * fsin(a)); } break;
     case 23: { float rr = fsqrt(r2), a = v_atan2(tx, ty), bd = 0.5f * (VP(0) - VP(1)); // blob: high low waves
@@ -295,8 +313,8 @@ __device__ __forceinline__ bool apply_variation_body(int id, float w, const floa
                float a = mwc_next_01(r) * 2.0f * FM_PI;
                tx += g * fcos(a); ty += g * fsin(a); } break;
     case 68: { float mx = VP(0), my = VP(1), xr = 2.0f * mx, yr = 2.0f * my;           // modulus: x y
-               float ax = (tx > mx) ? VW * (-mx + fmodf(tx + mx, xr)) : (tx < -mx) ? VW * (mx - fmodf(mx - tx, xr)) : VW * tx;
-               float ay = (ty > my) ? VW * (-my + fmodf(ty + my, yr)) : (ty < -my) ? VW * (my - fmodf(my - ty, yr)) : VW * ty;
+               float ax = (tx > mx) ? VW * (-mx + v_fmod(tx + mx, xr)) : (tx < -mx) ? VW * (mx - v_fmod(mx - tx, xr)) : VW * tx;
+               float ay = (ty > my) ? VW * (-my + v_fmod(ty + my, yr)) : (ty < -my) ? VW * (my - v_fmod(my - ty, yr)) : VW * ty;
                OUT(ax, ay); } break;
     case 69: { float tpf = 2.0f * FM_PI * VP(2);                                       // oscope: amplitude damping frequency separation
                float t = VP(0) * fexp(-fabsf(tx) * VP(1)) * fcos(tpf * tx) + VP(3);
