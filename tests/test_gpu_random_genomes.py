@@ -179,7 +179,7 @@ def _blocks16(a, dim):
 # uses 4096 trajectories (eight trajectories of a map that does not mix are not a distribution, and 64 are a poor
 # one: seed 176, cell + julian, is 0.046 from a 64-trajectory sample and 0.021 from 4096 — the error of the CPU
 # sample's basin weights); the two seeds that mix least get 65536 short trajectories, a sample made like the GPU's.
-@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102, 110, 176, 226])
+@pytest.mark.parametrize('seed', [209, 41, 48, 50, 102, 110, 176, 226, 270, 278, 295])
 def test_single_xform_genome_default_schedule(seed):
     gnm, prof = random_genome(seed)
     assert len(gnm['xforms']) == 1
