@@ -146,15 +146,48 @@ __host__ __device__ constexpr int spec_resident_sgprs()
     return n;
 }
 constexpr bool kSpecResident = FL_SPEC_NXF <= FL_RESIDENT_MAX_XF && spec_resident_sgprs() <= 48;
-template <int LO, int HI>
-__device__ __forceinline__ void spec_dispatch_res(int k, const XfHead (&heads)[FL_SPEC_NXF], const float *__restrict__ xf0, int xf_stride,
+// ... and what a round would otherwise rebuild from those scalars with VECTOR instructions, every round, lives in vector registers
+// for the launch: a VALU instruction reads at most one scalar register, so `fma(a, x, fma(b, y, c))` with a, b, c in scalar
+// registers costs a v_mov for c, and the colour blend `fma(col, 1 - speed, colour * speed)` computes its two wave-uniform
+// operands with a v_sub, a v_mov and a v_mul (there is no scalar float ALU): 3 + 2 + 2 of a small flame's ~74 vector instructions
+// per round.  Budget FL_HOIST_BUDGET registers (the 1536-slot geometry runs six waves per SIMD: 80 registers): the colour products
+// first (3 instructions per register), the camera's offsets, then the affine offsets if they fit.  Same operations on the same
+// values, done once: bit-identical.
+#ifndef FL_HOIST_BUDGET
+#define FL_HOIST_BUDGET 12
+#endif
+__host__ __device__ constexpr int spec_npost() { int n = 0; for (int i = 0; i < FL_SPEC_NXF; ++i) n += kSpecPost[i] != 0 ? 1 : 0; return n; }
+constexpr bool kHoistCol = kSpecResident && FL_SPEC_NXF + 2 <= FL_HOIST_BUDGET;
+constexpr bool kHoistAff = kHoistCol && 3 * FL_SPEC_NXF + 2 <= FL_HOIST_BUDGET;
+constexpr bool kHoistPost = kHoistAff && 3 * FL_SPEC_NXF + 2 + 2 * spec_npost() <= FL_HOIST_BUDGET;
+struct XfVec { float xo, yo, cprod, pxo, pyo; };
+// spec_apply_xf for a resident record: h.f[13] holds 1 - colour speed, v the vector-register copies
+template <int I>
+__device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &v, const float *__restrict__ xf,
                                                   float &x, float &y, float &c, mwc_t &r)
 {
-    if constexpr (HI - LO == 1) spec_apply_xf<LO>(heads[LO], xf0 + LO * xf_stride, x, y, c, r);
+    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, kHoistAff ? v.xo : h.f[2]));
+    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, kHoistAff ? v.yo : h.f[5]));
+    float ox = -0.0f, oy = -0.0f;
+    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
+    if constexpr (kSpecPost[I] != 0) {
+        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, kHoistPost ? v.pxo : h.f[8]));
+        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, kHoistPost ? v.pyo : h.f[11]));
+        ox = qx; oy = qy;
+    }
+    if constexpr (kHoistCol) c = fmaf(c, h.f[13], v.cprod);
+    else { const float csp = h.f[13]; c = fmaf(c, 1.0f - csp, h.f[12] * csp); }
+    x = ox; y = oy;
+}
+template <int LO, int HI>
+__device__ __forceinline__ void spec_dispatch_res(int k, const XfHead (&heads)[FL_SPEC_NXF], const XfVec (&hv)[FL_SPEC_NXF], const float *__restrict__ xf0, int xf_stride,
+                                                  float &x, float &y, float &c, mwc_t &r)
+{
+    if constexpr (HI - LO == 1) spec_apply_xf_res<LO>(heads[LO], hv[LO], xf0 + LO * xf_stride, x, y, c, r);
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, xf0, xf_stride, x, y, c, r);
-        else spec_dispatch_res<MID, HI>(k, heads, xf0, xf_stride, x, y, c, r);
+        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, hv, xf0, xf_stride, x, y, c, r);
+        else spec_dispatch_res<MID, HI>(k, heads, hv, xf0, xf_stride, x, y, c, r);
     }
 }
 
@@ -282,7 +315,11 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     if (!isfinite(fabsf(x) + fabsf(y))) reseed(x, y, color, rctx);          // iter.py:209-216
     __syncthreads();
     // camera and final xform are constant for the slot
-    const float cam0 = P[0], cam1 = P[1], cam2 = P[2], cam3 = P[3], cam4 = P[4], cam5 = P[5];
+    const float cam0 = P[0], cam1 = P[1], cam3 = P[3], cam4 = P[4];
+    float cam2 = P[2], cam5 = P[5];
+#ifdef FL_RTC
+    if constexpr (SPEC && FL_HOIST_BUDGET >= 2) asm volatile("" : "+v"(cam2), "+v"(cam5));      // the camera's offsets in vector registers (see kHoistCol)
+#endif
     const float *__restrict__ xf_final = P + xf_off + nxf * xf_stride;
 
     // Cumulative xform densities of this slot's temporal sample (constant for the launch), one
@@ -328,9 +365,20 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 #ifdef FL_RTC
     constexpr bool RESIDENT = SPEC && kSpecResident;
     XfHead heads[FL_SPEC_NXF];
+    XfVec hv[FL_SPEC_NXF] = {};
     if constexpr (RESIDENT) {
 #pragma unroll
-        for (int i = 0; i < FL_SPEC_NXF; ++i) heads[i] = load_head(P + xf_off + i * xf_stride);
+        for (int i = 0; i < FL_SPEC_NXF; ++i) {
+            heads[i] = load_head(P + xf_off + i * xf_stride);
+            if constexpr (kHoistCol) {
+                const float csp = heads[i].f[13];
+                hv[i].cprod = heads[i].f[12] * csp;
+                asm volatile("" : "+v"(hv[i].cprod));
+                heads[i].f[13] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f - csp)));
+            }
+            if constexpr (kHoistAff) { hv[i].xo = heads[i].f[2]; hv[i].yo = heads[i].f[5]; asm volatile("" : "+v"(hv[i].xo), "+v"(hv[i].yo)); }
+            if constexpr (kHoistPost) { hv[i].pxo = heads[i].f[8]; hv[i].pyo = heads[i].f[11]; asm volatile("" : "+v"(hv[i].pxo), "+v"(hv[i].pyo)); }
+        }
     }
 #else
     constexpr bool RESIDENT = false;
@@ -361,7 +409,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // on this kernel's critical path) and still has the swap, the barrier and the rest of the round to
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
-        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, P + xf_off, xf_stride, x, y, color, rctx);
+        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx);
         else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
 #endif

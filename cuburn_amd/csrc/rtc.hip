@@ -95,7 +95,7 @@ std::string spec_header(const IterSpec &s, int nw, bool count, int acc)
 
 bool rtc_available() { return api().ok; }
 
-int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err)
+int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt)
 {
     const Api &a = api();
     if (!a.ok) { *err = "libhiprtc not found"; return -1; }
@@ -137,6 +137,7 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
     };
     // FLAME_RTC_FLAGS="-mllvm -x=y ...": extra options for code-generation experiments (tools/exp_rtc_flags.sh)
     std::vector<const char *> optv(opts, opts + sizeof opts / sizeof *opts);
+    if (extra_opt) optv.push_back(extra_opt);
     std::vector<std::string> extra;
     if (const char *e = getenv("FLAME_RTC_FLAGS")) {
         std::string w;
@@ -180,13 +181,27 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int ac
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn = it->second.fn; return 0; }
-    std::vector<char> code;
-    if (rtc_compile(spec, nw, count, acc, &code, err)) return -1;
+    // Four-wave workgroups run six to a CU in the 1536-slot geometry (six waves per SIMD: 80 vector registers).  The kernel keeps
+    // wave-uniform operands of the round in vector registers (FL_HOIST_BUDGET, iter.hip); where that is what takes a genome's
+    // kernel past 80, it is compiled again with a smaller budget — a sixth of the workgroups waiting for a slot costs far more
+    // than the few instructions per round the registers save.
     Entry e;
-    if (hipModuleLoadData(&e.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); *err = "hipModuleLoadData failed"; return -1; }
-    if (hipModuleGetFunction(&e.fn, e.mod, "k_iter_spec") != hipSuccess) {
-        (void)hipGetLastError(); (void)hipModuleUnload(e.mod); *err = "k_iter_spec not found in the compiled module"; return -1;
+    const char *budgets[] = {nullptr, "-DFL_HOIST_BUDGET=5", "-DFL_HOIST_BUDGET=0"};
+    Entry first; bool have_first = false;
+    for (int b = 0; b < 3; ++b) {
+        std::vector<char> code;
+        if (rtc_compile(spec, nw, count, acc, &code, err, budgets[b])) { if (have_first) break; return -1; }
+        Entry t;
+        if (hipModuleLoadData(&t.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); *err = "hipModuleLoadData failed"; if (have_first) break; return -1; }
+        if (hipModuleGetFunction(&t.fn, t.mod, "k_iter_spec") != hipSuccess) {
+            (void)hipGetLastError(); (void)hipModuleUnload(t.mod); *err = "k_iter_spec not found in the compiled module"; if (have_first) break; return -1;
+        }
+        int regs = 0;
+        if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, t.fn) != hipSuccess) { (void)hipGetLastError(); regs = 0; }
+        if (nw != 4 || regs <= 80) { if (have_first) (void)hipModuleUnload(first.mod); have_first = false; e = t; break; }
+        if (!have_first) { first = t; have_first = true; } else (void)hipModuleUnload(t.mod);
     }
+    if (have_first) e = first;          // over 80 with every budget: the registers are not the hoisted operands — keep the full budget
     if (g_cache.size() >= kMaxModules) {
         // simple bound: drop THIS device's modules (the current device is `device`: its queued kernels are
         // waited for first); modules of other devices held by the process stay loaded — their kernels may
