@@ -175,7 +175,8 @@ __device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &
         const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, kHoistPost ? v.pyo : h.f[11]));
         ox = qx; oy = qy;
     }
-    if constexpr (kHoistCol) c = fmaf(c, h.f[13], v.cprod);
+    // (the empty asm keeps the blend in its xform's arm: merged into one v_fmac behind the arms it needs a v_mov of the product in each)
+    if constexpr (kHoistCol) { c = fmaf(c, h.f[13], v.cprod); asm volatile("" : "+v"(c)); }
     else { const float csp = h.f[13]; c = fmaf(c, 1.0f - csp, h.f[12] * csp); }
     x = ox; y = oy;
 }
@@ -512,7 +513,8 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         }
         const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
         // rint of a value in [0, 255] = the low mantissa bits of (value + 2^23): the float adder rounds to nearest even
-        const int ci = (int)((__float_as_uint(fminf(fmaxf(cf, 0.0f), 255.0f) + 8388608.0f) - 0x4b000000u) & 0xffu);
+        const uint32_t cbits = __float_as_uint(fminf(fmaxf(cf, 0.0f), 255.0f) + 8388608.0f);
+        const int ci = (int)((cbits - 0x4b000000u) & 0xffu);
         const u64 val = BINNED ? 0ull : palrow[ci];                         // iter.py:351
 
         // Every add returns the previous cell value, but the value is only looked at one
@@ -528,8 +530,12 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             // stage the record, count its bin; every R rounds the batch is sorted by bin in LDS
             // and written to this slot's private region of the sample log (no global atomics)
             const uint32_t bin = ok ? __umul24(iy >> FL_TILE_H_LOG2, bg.tiles_x) + (ix >> TWL) : bg.nbins;
-            const uint32_t pay = ((iy & (FL_TILE_H - 1u)) << (TWL + 8u)) | ((ix & ((1u << TWL) - 1u)) << 8) | (uint32_t)ci;
-            const uint32_t rec = WIDE ? pay : (bin << PAY_BITS) | pay;
+            // {bin | row | column} in three bytes, then ONE v_perm_b32 shifts them up a byte and drops the palette column — byte 0 of
+            // the rounded colour's bit pattern — underneath: two ands, two shift-ors and the permute, where masking and shifting every
+            // field into place took seven instructions + the colour's own mask
+            const uint32_t t1 = ((iy & (FL_TILE_H - 1u)) << TWL) | (ix & ((1u << TWL) - 1u));
+            const uint32_t t2 = WIDE ? t1 : (bin << (TWL + FL_TILE_H_LOG2)) | t1;
+            const uint32_t rec = __builtin_amdgcn_perm(t2, cbits, 0x06050400u);
             if (WIDE) skey[staged * NT + tid] = (uint16_t)bin;
             stage[staged * NT + tid] = rec;
             __hip_atomic_fetch_add(my_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
