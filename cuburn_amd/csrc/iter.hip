@@ -162,21 +162,23 @@ constexpr bool kHoistAff = kHoistCol && 3 * FL_SPEC_NXF + 2 <= FL_HOIST_BUDGET;
 constexpr bool kHoistPost = kHoistAff && 3 * FL_SPEC_NXF + 2 + 2 * spec_npost() <= FL_HOIST_BUDGET;
 struct XfVec { float xo, yo, cprod, pxo, pyo; };
 // spec_apply_xf for a resident record: h.f[13] holds 1 - colour speed, v the vector-register copies
-template <int I>
+// The final xform's record is constant for the slot as well: its operands are held the same way (three registers, five with a post affine).
+constexpr bool kHoistFinal = FL_SPEC_FINAL != 0 && FL_HOIST_BUDGET >= 7;
+template <int I, bool COL = kHoistCol, bool AFF = kHoistAff, bool POST = kHoistPost>
 __device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &v, const float *__restrict__ xf,
                                                   float &x, float &y, float &c, mwc_t &r)
 {
-    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, kHoistAff ? v.xo : h.f[2]));
-    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, kHoistAff ? v.yo : h.f[5]));
+    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, AFF ? v.xo : h.f[2]));
+    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, AFF ? v.yo : h.f[5]));
     float ox = -0.0f, oy = -0.0f;
     spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
     if constexpr (kSpecPost[I] != 0) {
-        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, kHoistPost ? v.pxo : h.f[8]));
-        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, kHoistPost ? v.pyo : h.f[11]));
+        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, POST ? v.pxo : h.f[8]));
+        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, POST ? v.pyo : h.f[11]));
         ox = qx; oy = qy;
     }
     // (the empty asm keeps the blend in its xform's arm: merged into one v_fmac behind the arms it needs a v_mov of the product in each)
-    if constexpr (kHoistCol) { c = fmaf(c, h.f[13], v.cprod); asm volatile("" : "+v"(c)); }
+    if constexpr (COL) { c = fmaf(c, h.f[13], v.cprod); asm volatile("" : "+v"(c)); }
     else { const float csp = h.f[13]; c = fmaf(c, 1.0f - csp, h.f[12] * csp); }
     x = ox; y = oy;
 }
@@ -381,6 +383,17 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             if constexpr (kHoistPost) { hv[i].pxo = heads[i].f[8]; hv[i].pyo = heads[i].f[11]; asm volatile("" : "+v"(hv[i].pxo), "+v"(hv[i].pyo)); }
         }
     }
+    XfHead hfin_res = {};
+    XfVec vfin = {};
+    if constexpr (SPEC && kHoistFinal) {
+        hfin_res = load_head(xf_final);
+        const float csp = hfin_res.f[13];
+        vfin.cprod = hfin_res.f[12] * csp;
+        vfin.xo = hfin_res.f[2]; vfin.yo = hfin_res.f[5];
+        asm volatile("" : "+v"(vfin.cprod), "+v"(vfin.xo), "+v"(vfin.yo));
+        hfin_res.f[13] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f - csp)));
+        if constexpr (kSpecPost[FL_SPEC_NXF] != 0) { vfin.pxo = hfin_res.f[8]; vfin.pyo = hfin_res.f[11]; asm volatile("" : "+v"(vfin.pxo), "+v"(vfin.pyo)); }
+    }
 #else
     constexpr bool RESIDENT = false;
 #endif
@@ -484,7 +497,8 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         float fx = x, fy = y, fc = color;
 #ifdef FL_RTC
         if constexpr (SPEC) {
-            if constexpr (FL_SPEC_FINAL != 0) { const XfHead hfin = load_head(xf_final); spec_apply_xf<FL_SPEC_NXF>(hfin, xf_final, fx, fy, fc, rctx); }
+            if constexpr (kHoistFinal) spec_apply_xf_res<FL_SPEC_NXF, true, true, true>(hfin_res, vfin, xf_final, fx, fy, fc, rctx);
+            else if constexpr (FL_SPEC_FINAL != 0) { const XfHead hfin = load_head(xf_final); spec_apply_xf<FL_SPEC_NXF>(hfin, xf_final, fx, fy, fc, rctx); }
         } else
 #endif
         if (has_final) { const XfHead hfin = load_head(xf_final); apply_xf(hfin, xf_final, var_stride, fx, fy, fc, rctx); }   // iter.py:302-307
