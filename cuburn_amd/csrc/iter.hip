@@ -59,6 +59,9 @@ __device__ __forceinline__ uint32_t shuffle_dest(uint32_t w, uint32_t l, uint32_
 // The first 18 words of an xform record (include/flame_hip.h (5)): affines, colour, structure
 // word, and the number + weight of the first variation.  Held in SGPRs.
 struct XfHead { float f[16]; int vid0; float w0; };
+#ifndef FL_XTAB_BYTES
+#define FL_XTAB_BYTES 256      /* LDS behind everything else: the per-xform operand table (kTab), 16 xforms */
+#endif
 
 __device__ __forceinline__ XfHead load_head(const float *__restrict__ xf) {
     XfHead h;
@@ -162,6 +165,39 @@ constexpr bool kHoistAff = kHoistCol && 3 * FL_SPEC_NXF + 2 <= FL_HOIST_BUDGET;
 constexpr bool kHoistPost = kHoistAff && 3 * FL_SPEC_NXF + 2 + 2 * spec_npost() <= FL_HOIST_BUDGET;
 struct XfVec { float xo, yo, cprod, pxo, pyo; };
 // spec_apply_xf for a resident record: h.f[13] holds 1 - colour speed, v the vector-register copies
+// Kernels whose records are fetched per round (more than FL_RESIDENT_MAX_XF xforms) cannot keep every xform's operands in registers; they keep
+// them in a 16-byte-per-xform LDS table {x offset, y offset, 1 - colour speed, colour * speed}, filled once per launch, and read the entry of the
+// NEXT round's xform (chosen a round ahead) behind the swap: one address instruction and one ds_read_b128 per round instead of the two v_mov of
+// the affine and the v_sub + v_mov + v_mul of the colour blend.
+constexpr bool kTab = !kSpecResident && FL_HOIST_BUDGET >= 12 && FL_SPEC_NXF * 16 <= FL_XTAB_BYTES;
+template <int I>
+__device__ __forceinline__ void spec_apply_xf_tab(const XfHead &h, const float4 &t, const float *__restrict__ xf,
+                                                  float &x, float &y, float &c, mwc_t &r)
+{
+    float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, t.x));
+    float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, t.y));
+    float ox = -0.0f, oy = -0.0f;
+    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
+    if constexpr (kSpecPost[I] != 0) {
+        const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, h.f[8]));
+        const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, h.f[11]));
+        ox = qx; oy = qy;
+    }
+    c = fmaf(c, t.z, t.w);
+    asm volatile("" : "+v"(c));
+    x = ox; y = oy;
+}
+template <int LO, int HI>
+__device__ __forceinline__ void spec_dispatch_tab(int k, const XfHead &h, const float4 &t, const float *__restrict__ xf,
+                                                  float &x, float &y, float &c, mwc_t &r)
+{
+    if constexpr (HI - LO == 1) spec_apply_xf_tab<LO>(h, t, xf, x, y, c, r);
+    else {
+        constexpr int MID = (LO + HI) / 2;
+        if (k < MID) spec_dispatch_tab<LO, MID>(k, h, t, xf, x, y, c, r);
+        else spec_dispatch_tab<MID, HI>(k, h, t, xf, x, y, c, r);
+    }
+}
 // The final xform's record is constant for the slot as well: its operands are held the same way (three registers, five with a post affine).
 constexpr bool kHoistFinal = FL_SPEC_FINAL != 0 && FL_HOIST_BUDGET >= 7;
 template <int I, bool COL = kHoistCol, bool AFF = kHoistAff, bool POST = kHoistPost>
@@ -291,6 +327,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     const uint32_t CNTW = (bg.nbins + 1 + 3) & ~3u;
     uint32_t *s_nvalid = cnt + SETS * CNTW;                                      // [4]
     uint32_t *tot = s_nvalid + 4;                                                      // [128] totals of 64-tile chunks
+    // behind everything else (in FRONT it moved every other address off its immediate offsets: +6 registers): the per-xform operand
+    // table of the per-genome kernels whose records are fetched per round, see kTab
+    float4 *xtab = BINNED ? reinterpret_cast<float4 *>(tot + 128) : reinterpret_cast<float4 *>(palrow + FL_PAL_W);
     uint32_t *my_cnt = cnt + ((threadIdx.x & 63u) % SETS) * CNTW;
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -398,6 +437,18 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     constexpr bool RESIDENT = false;
 #endif
     XfHead hnext = RESIDENT ? XfHead{} : load_head(xf_next);
+    float4 tcur = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef FL_RTC
+    if constexpr (SPEC && kTab) {
+        if ((int)tid < FL_SPEC_NXF) {
+            const float *__restrict__ rr = P + xf_off + (int)tid * xf_stride;
+            const float csp = rr[13];
+            xtab[tid] = make_float4(rr[2], rr[5], 1.0f - csp, rr[12] * csp);
+        }
+        __syncthreads();
+        tcur = xtab[k_next];
+    }
+#endif
 
     // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
     uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
@@ -424,6 +475,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
         if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx);
+        else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx);
         else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
 #endif
@@ -443,6 +495,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             swp[par][0][dst] = x; swp[par][1][dst] = y; swp[par][2][dst] = color;
             __syncthreads();
             x = swp[par][0][tid]; y = swp[par][1][tid]; color = swp[par][2][tid];
+#endif
+#ifdef FL_RTC
+            if constexpr (SPEC && kTab) tcur = xtab[k_next];          // the next round's operands: on their way while this round plots
 #endif
 #if FL_ITER_PRIO
             __builtin_amdgcn_s_setprio(0);
@@ -795,9 +850,9 @@ static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
     if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + (nw == 4 ? FL_CNT_SETS : FL_CNT_SETS_BIG) * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16
-             + (((nbins + 64u) >> 6) > FL_SCAN_SERIAL_MAX ? 128 * 4 : 0);      // chunk totals: only the all-waves scan uses them
+             + 128 * 4;      // chunk totals (only the all-waves scan uses them; the operand table sits behind them either way)
     else b += FL_PAL_W * 8;
-    return b;
+    return b + FL_XTAB_BYTES;
 }
 
 void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,

@@ -186,9 +186,9 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int ac
     // kernel past 80, it is compiled again with a smaller budget — a sixth of the workgroups waiting for a slot costs far more
     // than the few instructions per round the registers save.
     Entry e;
-    const char *budgets[] = {nullptr, "-DFL_HOIST_BUDGET=5", "-DFL_HOIST_BUDGET=0"};
+    const char *budgets[] = {nullptr, "-DFL_HOIST_BUDGET=7", "-DFL_HOIST_BUDGET=5", "-DFL_HOIST_BUDGET=0"};
     Entry first; bool have_first = false;
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 4; ++b) {
         std::vector<char> code;
         if (rtc_compile(spec, nw, count, acc, &code, err, budgets[b])) { if (have_first) break; return -1; }
         Entry t;
