@@ -188,8 +188,17 @@ __host__ __device__ constexpr DeHCombos de_hcombos(int P)
 #ifndef DE_FAST_PREP
 #define DE_FAST_PREP 1
 #endif
+#ifndef DE_RUN
+#define DE_RUN 8u             /* tile order 2: tiles per run (a run stays on one XCD) */
+#endif
+#ifndef DE_INTERIOR_LOADS
+#define DE_INTERIOR_LOADS 1   /* tiles that touch no image edge load their staged region without clamps, one address per thread */
+#endif
 #ifndef DE_LANE_GROUPS
 #define DE_LANE_GROUPS 1      /* 16-pixel rows: one row per hardware lane group of ds_read_b128 (see de_out_px) */
+#endif
+#ifndef DE_LANE_PAIRS
+#define DE_LANE_PAIRS 1       /* 8-pixel rows of the half-slope directions: two rows 8 slots apart per hardware lane group */
 #endif
 struct DeReach { int hu, hv; };
 // Largest row / column displacement (sheared coordinates) of any staged value a tile pixel needs:
@@ -235,7 +244,9 @@ template <int P> struct DeGeo {
     // (The horizontal direction keeps element = it * NT + tid: two iterations of 112-pixel rows, divisions that cost
     // little, and a border path that has no registers left for per-thread constants.)
     static constexpr bool ROWWISE = P != 0;
-    static constexpr int RS = NT / COLS, NACT = ROWWISE ? RS * COLS : NT;
+    // (odd K: an even number of rows per iteration, so that a thread's rows keep their parity — its tap offsets — and its
+    // global address advances by the same amount from iteration to iteration: floor((u + RS) * K / 2) = floor(u * K / 2) + RS * K / 2)
+    static constexpr int RS = (K & 1) ? (NT / COLS) & ~1 : NT / COLS, NACT = ROWWISE ? RS * COLS : NT;
     static constexpr int NIT = ROWWISE ? (ROWS + RS - 1) / RS : (NPX + NT - 1) / NT;
     // plane A (normalised pixels) holds only the rows the taps themselves read (r = -16 .. 16), with the staged
     // region's columns: the outer rows are needed as densities for the blurs, not as pixels
@@ -244,8 +255,15 @@ template <int P> struct DeGeo {
     static_assert(HA <= HU, "the taps reach no further than the blurs");
     // plane B (per-pixel tap terms): the positions of the taps themselves
     static constexpr int HBU = de_reach(P, false).hu, HBV = de_reach(P, false).hv;
-    static constexpr int BROWS = TH + 2 * HBU, BCOLS = TW + 2 * HBV, NPXB = BROWS * BCOLS;
-    static constexpr int RSB = NT / BCOLS, NACTB = ROWWISE ? RSB * BCOLS : NT;
+    // BSTR: plane B's row stride.  A ds_read_b128 is served in four groups of 16 lanes, each conflict-free when its 16 float4 slots
+    // differ mod 16; with 8-pixel rows a group holds two rows (de_out_px), which must then lie 8 slots apart mod 16: rows two apart
+    // on a stride of 12 (plane A of directions 4 / 6: 8 + 2 * 2 columns) or of 10 with the equal-parity rows of directions 5 / 7 — plane B
+    // of directions 4 / 6 has 10 columns and rows two apart, hence two columns of padding (round 5: its reads took 12 LDS cycles, not 4).
+    static constexpr int BROWS = TH + 2 * HBU, BCOLS = TW + 2 * HBV;
+    static constexpr int BPAD = (!de_hoisted(P) && (K & 1) == 0 && TW == 8 && DE_LANE_PAIRS) ? 12 - BCOLS : 0;
+    static constexpr int BSTR = BCOLS + BPAD, NPXB = BROWS * BSTR;
+    static_assert(BPAD >= 0 && (BPAD == 0 || (2 * BSTR) % 16 == 8), "rows two apart must lie 8 float4 slots apart mod 16");
+    static constexpr int RSB = (K & 1) ? (NT / BCOLS) & ~1 : NT / BCOLS, NACTB = ROWWISE ? RSB * BCOLS : NT;
     static constexpr int NITB = ROWWISE ? (BROWS + RSB - 1) / RSB : (NPXB + NT - 1) / NT;
     // LDS: A float4[NPXA] | B float4[NPXB] | (integer-step directions) the fast path's density plane float[NPX];
     // the nested preparation's two dense float planes live in B's space
@@ -257,7 +275,7 @@ template <int P> struct DeGeo {
     static constexpr int SPAN = de_shear(P, TH - 1) < 0 ? -de_shear(P, TH - 1) : de_shear(P, TH - 1);
     // element offset of image displacement (dx, dy) from a position in a row of parity par
     static constexpr int off(int par, int dx, int dy) { return dy * COLS + de_dv(P, par, dx, dy); }
-    static constexpr int offb(int par, int dx, int dy) { return dy * BCOLS + de_dv(P, par, dx, dy); }
+    static constexpr int offb(int par, int dx, int dy) { return dy * BSTR + de_dv(P, par, dx, dy); }
     static constexpr int tap_off(int par, int r) { return off(par, de_dx(P, r), de_dy(P, r)); }
     static constexpr int tap_offb(int par, int r) { return offb(par, de_dx(P, r), de_dy(P, r)); }
     static constexpr int min_tap_off(int par)
@@ -331,6 +349,17 @@ __device__ __forceinline__ void de_out_px(int wv, int lane, int &ou, int &ov)
         ov = ((q >> 1) << 2) | (lane & 3);
         ou = (G::K & 1) ? (wv >> 1) * 8 + (wv & 1) + 2 * rw : wv * 4 + rw;
     }
+    else if (G::TW == 8 && !G::HOIST && DE_LANE_PAIRS) {
+        // 8-pixel rows, eight to a wave (the half-slope directions).  A hardware group of 16 lanes (quads {0, 3, 5, 6} or {1, 2, 4, 7}
+        // of each half of the wave) takes TWO rows, two apart among the wave's eight: on the planes' strides (DeGeo::BSTR) their
+        // float4 slots are 8 apart mod 16 and every read of the tap loop is served in 4 LDS cycles (tools/de_geometry_model.py;
+        // before: A 8 / B 12 cycles for directions 4 / 6, 8 / 8 for 5 / 7).
+        const int q = (lane & 31) >> 2, grp = (q ^ (q >> 1) ^ (q >> 2)) & 1, rank = q >> 1;
+        const int gi = 2 * (lane >> 5) + grp;                                 // group within the wave
+        const int k = (gi >> 1) * 4 + (gi & 1) + 2 * (rank >> 1);             // row among the wave's eight
+        ov = ((rank & 1) << 2) | (lane & 3);
+        ou = (G::K & 1) ? (wv >> 1) * 16 + (wv & 1) + 2 * k : wv * 8 + k;
+    }
     else if (G::K & 1) {
         constexpr int RPW = 64 / G::TW;                                   // rows per wave (equal parity)
         ou = (wv >> 1) * (2 * RPW) + (wv & 1) + 2 * (lane / G::TW); ov = lane % G::TW;
@@ -389,7 +418,7 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     int ou, ov;
     de_out_px<P>(wv, de_lane_here(), ou, ov);
     const int ci = (ou + G::HA) * G::COLS + ov + G::HV;
-    const int cb = (ou + G::HBU) * G::BCOLS + ov + G::HBV;
+    const int cb = (ou + G::HBU) * G::BSTR + ov + G::HBV;
     constexpr int MINOFF = G::min_tap_off(PAR), MINOFFB = G::min_tap_offb(PAR);
 #define TOFF(r) (G::tap_off(PAR, (r)) - MINOFF)
 #define TOFFB(r) (G::tap_offb(PAR, (r)) - MINOFFB)
@@ -617,6 +646,15 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
     uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
     // (tail.order = 1, FLAME_DE_ORDER=1: plain row-major order — tile t = workgroup t, rows of tiles left to right)
     if (tail.order == 1) { const uint32_t tiles_x = ntiles / tiles_y; t = blockIdx.x < ntiles ? (blockIdx.x % tiles_x) * tiles_y + blockIdx.x / tiles_x : ntiles; }
+    // (tail.order = 2: row-major in RUNS — DE_RUN consecutive tiles of a row of tiles go to ONE XCD, the next run to the next XCD.  Plain
+    // row-major order deals neighbouring tiles to eight different L2s, and the flat, wide staged regions of directions 0 / 4 / 6 share
+    // most of their cache lines with their left and right neighbours: 4.2x the image fetched into the L2s per launch, real HBM traffic
+    // once the image has outgrown the Infinity Cache.)
+    if (tail.order == 2) {
+        const uint32_t tiles_x = ntiles / tiles_y, loc = blockIdx.x >> 3;
+        const uint32_t rm = ((loc / DE_RUN) * 8u + xcd) * DE_RUN + loc % DE_RUN;
+        t = rm < ntiles ? (rm % tiles_x) * tiles_y + rm / tiles_x : ntiles;
+    }
     if (t >= ntiles) return;
 #endif
 #if !DE_CHAIN_BUILD
@@ -650,11 +688,14 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
 #define DE_B_THREAD() int tb_ = tid; asm volatile("" : "+v"(tb_)); \
     const int br0 = G::ROWWISE ? tb_ / G::BCOLS : 0, bc0 = tb_ - br0 * G::BCOLS; const bool bact = tb_ < G::NACTB; \
     const int bidx0 = (br0 + G::HU - G::HBU) * G::COLS + bc0 + G::HV - G::HBV;      /* staged element of this thread's plane-B element, iteration 0 */ \
-    /* plane-B element `it` of this thread: its index, its staged element, staged row and column */ \
+    const int bsto0 = br0 * G::BSTR + bc0;                                          /* ... and where it is stored (rows of BSTR float4) */ \
+    /* plane-B element `it` of this thread: its index in the plane, its staged element, staged row and column */ \
     auto b_elem = [&](int it, int &bidx, int &idx, int &ul, int &vl) __attribute__((always_inline)) -> bool { \
-        bidx = it * G::NACTB + tid; \
         if (G::ROWWISE) { const int ub = it * G::RSB + br0; ul = ub + G::HU - G::HBU; vl = bc0 + G::HV - G::HBV; \
+                          bidx = bsto0 + it * G::RSB * G::BSTR; \
                           idx = bidx0 + it * G::RSB * G::COLS; return bact && ub < G::BROWS; } \
+        static_assert(G::ROWWISE || G::BSTR == G::BCOLS, "padding only with row-wise staging"); \
+        bidx = it * G::NACTB + tid; \
         const int ub = bidx / G::BCOLS, vb = bidx - ub * G::BCOLS; \
         ul = ub + G::HU - G::HBU; vl = vb + G::HV - G::HBV; idx = ul * G::COLS + vl; return bidx < G::NPXB; }
 
@@ -725,6 +766,19 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
     float4 tn[G::NIT];
     {
     DE_S_THREAD();
+    if (G::ROWWISE && !border && DE_INTERIOR_LOADS) {
+        // no staged position leaves the image: no clamps, and a thread's element of iteration `it` lies it * RS rows below its
+        // first one — one address per thread, a wave-uniform step per iteration (RS * K is even, see DeGeo::RS)
+        const int u0 = sr0 - G::HU;
+        const uint32_t g0 = (uint32_t)((by0 + u0) * (int)d.astride + bx0 + ((u0 * G::K) >> 1) + sc0 - G::HV);
+        const uint32_t gstep = (uint32_t)(G::RS * (int)d.astride + G::RS * G::K / 2);
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int nrows = G::ROWS - it * G::RS < G::RS ? G::ROWS - it * G::RS : G::RS;       // rows of this iteration (threads beyond them idle)
+            if (sr0 < nrows) tn[it] = DE_IN_PX(N.ld(g0 + (uint32_t)it * gstep));
+            else tn[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else {
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
         int ul, vl;
@@ -732,6 +786,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
         const int gx = de_clampi(bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, 0, xmax);
         const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
         tn[it] = DE_IN_PX(N.ld((uint32_t)(gy * (int)d.astride + gx)));
+    }
     }
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
@@ -936,7 +991,8 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
     ensure_max_dynamic_lds((const void *)k_de_dir<P, IN, OUT>, attr);
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
-    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(8 * ((ntiles + 7) / 8)), dim3(G::NT), de_lds_for_residency(G::LDS, G::NT, ntiles, P), st, d, Nout, N, kc, spk,
+    const uint32_t gran = tail.order == 2 ? 8u * DE_RUN : 8u;      // whole runs on every XCD
+    hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(gran * ((ntiles + gran - 1) / gran)), dim3(G::NT), de_lds_for_residency(G::LDS, G::NT, ntiles, P), st, d, Nout, N, kc, spk,
                        cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
 }
 
@@ -960,13 +1016,21 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     const float cs2 = 1.0f / (-1.41421353816986f * 3.0f * cstd) * 1.44269502162933f;      // exp(c*x) = exp2(c*log2e*x)
     const float ads = fabsf(-0.5f / dstd);
     DeTail none = {};
-    // Tile order.  The (near-)horizontal directions 0, 4 and 6 stage wide and flat regions: their tiles run in plain row-major
-    // order (workgroup b = tile b of the row of tiles), the others in per-XCD column-major runs (vertical neighbours, which
-    // share halo rows, on one XCD's L2).  Measured per direction (profiles/r04_de_order_prof.txt): row-major 43.0 / 66.0 /
-    // 65.9 us against 48.5 / 72.3 / 71.5 for directions 0 / 4 / 6, and 44.7-65.6 against 40.5-61.2 for the other five.
-    // FLAME_DE_ORDER=0|1 forces one order for every direction.
-    static const int forced = getenv("FLAME_DE_ORDER") ? atoi(getenv("FLAME_DE_ORDER")) : -1;
-    const int order = forced >= 0 ? forced : (pattern == 0 || pattern == 4 || pattern == 6) ? 1 : 0;
+    // Tile order, per direction and image size (profiles/r05_de_order.txt; round 4's table: profiles/r04_de_order_prof.txt).
+    //   0: per-XCD column-major runs (vertical neighbours, which share halo rows, on one XCD's L2) — directions 1, 5, 7, whose
+    //      staged regions are tall and narrow;
+    //   2: row-major in runs of DE_RUN tiles per XCD — directions 0, 4, 6 (flat, wide staged regions) and the diagonals 2, 3
+    //      (rows of a tile start one pixel further along: horizontal neighbours share most cache lines).  Round 4 ran 0 / 4 / 6 in
+    //      plain row-major order (1), which deals neighbouring tiles to eight different L2s: 4.2x the image fetched per launch.
+    // Above the Infinity Cache's 256 MiB (8K: 537 MB per image) a line fetched twice is HBM traffic twice, and directions 5 / 7 are
+    // better off in runs as well (8K: 854-864 us against 867-875; 4K and 1080p: 0-3 % the other way).
+    // 1080p: 415 us per chain with this table against 430 with round 4's; 4K 1428 / 1442; 8K 5699 / 5807.
+    // FLAME_DE_ORDER: one digit for every direction, or eight digits, one per direction.
+    static const char *forced_s = getenv("FLAME_DE_ORDER");
+    const int forced = !forced_s || !*forced_s ? -1 : (strlen(forced_s) == 8 ? forced_s[pattern] - '0' : forced_s[0] - '0');
+    const bool beyond_mall = (size_t)d.astride * d.ah * 16u > ((size_t)256 << 20);
+    const int table = (pattern == 1) ? 0 : (pattern == 5 || pattern == 7) ? (beyond_mall ? 2 : 0) : 2;
+    const int order = forced >= 0 && forced <= 2 ? forced : table;
     none.order = order;
     DeTail tl = tail ? *tail : none;
     tl.order = order;
