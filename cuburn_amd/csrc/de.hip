@@ -188,6 +188,12 @@ __host__ __device__ constexpr DeHCombos de_hcombos(int P)
 #ifndef DE_FAST_PREP
 #define DE_FAST_PREP 1
 #endif
+#ifndef DE_X_NOBORDER_EVAL
+#define DE_X_NOBORDER_EVAL 0  /* timing build (wrong results at the image edges): no direct evaluation of the blurs at clamped positions */
+#endif
+#ifndef DE_SKIP_OUTSIDE
+#define DE_SKIP_OUTSIDE 1
+#endif
 #ifndef DE_RUN
 #define DE_RUN 8u             /* tile order 2: tiles per run (a run stays on one XCD) */
 #endif
@@ -273,6 +279,13 @@ template <int P> struct DeGeo {
     static constexpr int MINW = HPL ? DE_MINW_H : DE_MINW;
     static constexpr size_t LDS = (size_t)(NPXA + NPXB) * 16 + (de_hoisted(P) ? (size_t)NPX * 4 : 0) + (HPL ? (size_t)NPXB * 32 : 0) + 64;
     static constexpr int SPAN = de_shear(P, TH - 1) < 0 ? -de_shear(P, TH - 1) : de_shear(P, TH - 1);
+    // Frame tables (tiles that touch an image edge, see "frame tables" in the kernel): every staged position outside the image clamps
+    // to a position ON the image's frame — (0 | xmax, clamped row) or (x, 0 | ymax) — so a tile needs the blurs at no more than
+    // 2 * ROWS + 2 * XS frame positions: one per staged row and side, one per x of the staged region's extent and side.
+    static constexpr int SHMIN = de_shear(P, -HU) < de_shear(P, ROWS - 1 - HU) ? de_shear(P, -HU) : de_shear(P, ROWS - 1 - HU);
+    static constexpr int SHMAX = de_shear(P, -HU) < de_shear(P, ROWS - 1 - HU) ? de_shear(P, ROWS - 1 - HU) : de_shear(P, -HU);
+    static constexpr int XS = COLS + SHMAX - SHMIN, NF = 2 * ROWS + 2 * XS;
+    static_assert((2 * NPX + 2 * NF) * 4 <= NPXB * 16, "preparation planes + frame tables must fit into plane B's space");
     // element offset of image displacement (dx, dy) from a position in a row of parity par
     static constexpr int off(int par, int dx, int dy) { return dy * COLS + de_dv(P, par, dx, dy); }
     static constexpr int offb(int par, int dx, int dy) { return dy * BSTR + de_dv(P, par, dx, dy); }
@@ -316,6 +329,20 @@ __device__ float de_b2_global(const IMG &N, const fl_dim &d, int cx, int cy, con
     for (int i = 0; i < 7; ++i) {
         const int x = de_clampi(cx + de_dx(P, 2 * (i - 3)), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, 2 * (i - 3)), 0, (int)d.ah - 1);
         den += de_b1_global<P>(N, d, x, y, k) * k.k[i];
+    }
+    return den;
+}
+// ... both blurs at once: the second blur's middle term (i = 3, t(0) = 0) IS the first blur at the position itself
+template <int P, class IMG>
+__device__ float de_b12_global(const IMG &N, const fl_dim &d, int cx, int cy, const DeCoefs &k, float &b1)
+{
+    float den = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int x = de_clampi(cx + de_dx(P, 2 * (i - 3)), 0, (int)d.astride - 1), y = de_clampi(cy + de_dy(P, 2 * (i - 3)), 0, (int)d.ah - 1);
+        const float v = de_b1_global<P>(N, d, x, y, k);
+        if (i == 3) b1 = v;
+        den += v * k.k[i];
     }
     return den;
 }
@@ -437,7 +464,12 @@ __device__ __forceinline__ void de_tap_loop(const float4 *__restrict__ sA, const
     // centre, but it cannot be factored out of the loop: for a narrow colour kernel (cstd < ~0.03) or
     // colours above 1 the partial exponent reaches +150 and 2^(cs*|c|^2) underflows — the sums overflow
     // to inf and come back as NaN / 0 (found by tools/soak_filters.py; the full exponent is never positive).
-    const float m2 = cen_live ? -2.0f * cs2 : 0.0f;
+    // (-2 cs is wave-uniform and the same in every form of the loop: left alone the compiler computes it once, ahead of the forms'
+    // branches, and holds — in one kernel spills — a vector register across all of them)
+    float cs2h = cs2;
+    asm volatile("" : "+s"(cs2h));
+    const float m2u = -2.0f * cs2h;
+    const float m2 = cen_live ? m2u : 0.0f;
     float Cx = ccx * m2, Cy = ccy * m2, Cz = ccz * m2;
     const float Kp = 0.5f * cs2;
     float Dl = cen_live ? cs2 * fmaf(ccz, ccz, fmaf(ccy, ccy, ccx * ccx)) - Kp : 0.0f;     // y_q * Dl: the centre term of a live pair
@@ -619,13 +651,14 @@ __device__ __forceinline__ void de_tile(const fl_dim &d, const IMG &Nout, const 
     float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPXA * 16);
     float *sW = reinterpret_cast<float *>(sB);                   // nested prep: dense density plane ...
     float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
+    float *sF1 = s1 + G::NPX, *sF2 = sF1 + G::NF;                // frame tables (border tiles): first / second blur at frame positions
     float *sWf = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16);      // fast prep: density plane beside B
 #else
 #define DE_IN_PX(p) de_in_px<IN>(p)
 template <int P, int IN, int OUT>
 __global__ void __launch_bounds__(DeGeo<P>::NT, DeGeo<P>::MINW)      // 8 waves per SIMD (<= 64 registers): 32 waves per CU in workgroups of NT threads
 k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, DeCoefs kc, DeSpatial spk,
-         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, DeTail tail)
+         float cs2, float ads, float dpow, float gspeed, uint32_t tiles_y, uint32_t ntiles, uint32_t tiles_x, uint32_t magic, DeTail tail)
 {
     using G = DeGeo<P>;
     static_assert(2 * G::NPX * 4 <= G::NPXB * 16, "the preparation planes must fit into plane B's space");
@@ -634,6 +667,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
     float4 *sB = reinterpret_cast<float4 *>(smem + (size_t)G::NPXA * 16);
     float *sW = reinterpret_cast<float *>(sB);                   // nested prep: dense density plane ...
     float *s1 = sW + G::NPX;                                     // ... and first blur (both die before B is written)
+    float *sF1 = s1 + G::NPX, *sF2 = sF1 + G::NF;                // frame tables (border tiles): first / second blur at frame positions
     float *sWf = reinterpret_cast<float *>(smem + (size_t)(G::NPXA + G::NPXB) * 16);      // fast prep: density plane beside B
     const DeImgPlain N = {const_cast<float4 *>(N_)}, Nout = {Nout_};
 
@@ -642,23 +676,27 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
     // neighbours and find each other's halo rows in that XCD's L2.
     // Tiles at the image's sides are the slow ones (staged positions outside the image evaluate their blurs on
     // the global image): XCDs 4..7 walk their run backwards, so that the right edge is done first, not last.
+    // (one division per workgroup, by tiles_y or tiles_x, as a multiplication by the host's `magic` = floor(2^32 / divisor) + 1: the
+    // three 32-bit divisions this used to take were ~100 dependent scalar instructions in front of a workgroup's first load)
     const uint32_t per_xcd = (ntiles + 7u) / 8u, xcd = blockIdx.x & 7u;
-    uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
-    // (tail.order = 1, FLAME_DE_ORDER=1: plain row-major order — tile t = workgroup t, rows of tiles left to right)
-    if (tail.order == 1) { const uint32_t tiles_x = ntiles / tiles_y; t = blockIdx.x < ntiles ? (blockIdx.x % tiles_x) * tiles_y + blockIdx.x / tiles_x : ntiles; }
-    // (tail.order = 2: row-major in RUNS — DE_RUN consecutive tiles of a row of tiles go to ONE XCD, the next run to the next XCD.  Plain
-    // row-major order deals neighbouring tiles to eight different L2s, and the flat, wide staged regions of directions 0 / 4 / 6 share
-    // most of their cache lines with their left and right neighbours: 4.2x the image fetched into the L2s per launch, real HBM traffic
-    // once the image has outgrown the Infinity Cache.)
-    if (tail.order == 2) {
-        const uint32_t tiles_x = ntiles / tiles_y, loc = blockIdx.x >> 3;
-        const uint32_t rm = ((loc / DE_RUN) * 8u + xcd) * DE_RUN + loc % DE_RUN;
-        t = rm < ntiles ? (rm % tiles_x) * tiles_y + rm / tiles_x : ntiles;
+    int tx, ty;
+    if (tail.order == 0) {
+        const uint32_t t = xcd * per_xcd + (xcd < 4u ? (blockIdx.x >> 3) : per_xcd - 1u - (blockIdx.x >> 3));
+        if (t >= ntiles) return;
+        const uint32_t q = tiles_y == 1u ? t : __umulhi(t, magic);      // t / tiles_y (a divisor of 1 has no 32-bit magic)
+        tx = (int)q; ty = (int)(t - q * tiles_y);
+    } else {
+        // tail.order = 1 (FLAME_DE_ORDER=1): plain row-major order — tile t = workgroup t, rows of tiles left to right.
+        // tail.order = 2: row-major in RUNS — DE_RUN consecutive tiles of a row of tiles go to ONE XCD, the next run to the next XCD.
+        // Plain row-major order deals neighbouring tiles to eight different L2s, and the flat, wide staged regions of directions
+        // 0 / 4 / 6 share most of their cache lines with their left and right neighbours: 4.2x the image fetched into the L2s per
+        // launch, real HBM traffic once the image has outgrown the Infinity Cache.
+        const uint32_t loc = blockIdx.x >> 3;
+        const uint32_t rm = tail.order == 1 ? blockIdx.x : ((loc / DE_RUN) * 8u + xcd) * DE_RUN + loc % DE_RUN;
+        if (rm >= ntiles) return;
+        const uint32_t q = tiles_x == 1u ? rm : __umulhi(rm, magic);    // rm / tiles_x
+        ty = (int)q; tx = (int)(rm - q * tiles_x);
     }
-    if (t >= ntiles) return;
-#endif
-#if !DE_CHAIN_BUILD
-    const int tx = (int)(t / tiles_y), ty = (int)(t % tiles_y);
 #endif
     // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
     const int bx0 = tx * G::TW - (G::K > 0 ? G::SPAN : 0), by0 = ty * G::TH;
@@ -743,6 +781,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
             }
         }
         __syncthreads();
+        DE_X_STOP(1)
         DE_PHASE(0);
         DE_B_THREAD();
 #pragma unroll
@@ -760,6 +799,7 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
             sB[bidx] = make_float4(ads * de_pow(n.w, dpow), n.w > 0.0f ? 1.0f : 0.0f, yk - fexp2(g), yk - fexp2(-g));
         }
         __syncthreads();
+        DE_X_STOP(4)
         DE_PHASE(2);
     } else {
     // ---- S0: stage N (edge-clamped) and the dense density plane ------------------------------
@@ -787,6 +827,45 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
         const int gy = de_clampi(by0 + ul - G::HU, 0, ymax);
         tn[it] = DE_IN_PX(N.ld((uint32_t)(gy * (int)d.astride + gx)));
     }
+    }
+    // ---- frame tables --------------------------------------------------------------------------
+    // A staged position outside the image takes the blurs AT its clamped position (the reference clamps the fetch from the blurred
+    // texture), which has to be evaluated on the global image: 7 loads for the first blur, 49 for both.  Round 4 did that wherever a
+    // staged position was virtual — every wave-iteration of S1 / S2 with one such lane ran the whole sequence, and at 1080p, where one
+    // tile in six touches an edge, this was 52 of the chain's 414 us (profiles/r05_de_border.txt).  All positions outside the image
+    // clamp to positions ON its frame, many to the same one: the tile evaluates each frame position it can need ONCE (one thread per
+    // position, its loads issued behind the tile's own, which are still in flight) and S1 / S2 look the values up.
+    // Same functions on the same arguments as before: same bits.
+    if (border && !DE_X_NOBORDER_EVAL) {
+        const int x0a = bx0 - G::HV, nrows_top = min(G::ROWS, G::HU - by0), first_bot = max(0, ymax + 1 - (by0 - G::HU));
+        // x extent of the staged rows above / below the image (shear is monotonic in the row)
+        int tlo = 1, thi = 0, blo = 1, bhi = 0;
+        if (nrows_top > 0) {
+            const int a = x0a + de_shear(P, -G::HU), b = x0a + (((nrows_top - 1 - G::HU) * G::K) >> 1);
+            tlo = min(a, b); thi = max(a, b) + G::COLS - 1;
+        }
+        if (first_bot < G::ROWS) {
+            const int a = x0a + (((first_bot - G::HU) * G::K) >> 1), b = x0a + de_shear(P, G::ROWS - 1 - G::HU);
+            blo = min(a, b); bhi = max(a, b) + G::COLS - 1;
+        }
+        for (int e = tid; e < G::NF; e += G::NT) {
+            int fx, fy; bool need;
+            if (e < 2 * G::ROWS) {                                       // (0 | xmax, row): rows whose staged span sticks out on that side
+                const int side = e >= G::ROWS, u = e - side * G::ROWS;
+                const int x0 = x0a + (((u - G::HU) * G::K) >> 1);
+                need = side ? x0 + G::COLS - 1 > xmax : x0 < 0;
+                fx = side ? xmax : 0; fy = de_clampi(by0 + u - G::HU, 0, ymax);
+            } else {                                                     // (x, 0 | ymax): x inside the image, under a staged row above / below it
+                const int e2 = e - 2 * G::ROWS, side = e2 >= G::XS;
+                fx = x0a + G::SHMIN + e2 - side * G::XS; fy = side ? ymax : 0;
+                need = fx >= 0 && fx <= xmax && (side ? (fx >= blo && fx <= bhi) : (fx >= tlo && fx <= thi));
+            }
+            if (need) {
+                float b1;
+                sF2[e] = de_b12_global<P>(N, d, fx, fy, kc, b1);
+                sF1[e] = b1;
+            }
+        }
     }
 #pragma unroll
     for (int it = 0; it < G::NIT; ++it) {
@@ -819,10 +898,10 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
             const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
             den = fmaf(sW[idx + o], kc.k[j], den);
         }
-        if (border) {
+        if (border && !DE_X_NOBORDER_EVAL) {
             const int gxu = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gyu = by0 + ul - G::HU;
             if (gxu < 0 || gxu > xmax || gyu < 0 || gyu > ymax)         // virtual position: the blur AT the clamped position
-                den = de_b1_global<P>(N, d, de_clampi(gxu, 0, xmax), de_clampi(gyu, 0, ymax), kc);
+                den = sF1[gxu < 0 ? ul : gxu > xmax ? G::ROWS + ul : 2 * G::ROWS + (gyu < 0 ? 0 : G::XS) + gxu - (bx0 - G::HV + G::SHMIN)];
         }
         s1[idx] = den;
     }
@@ -850,10 +929,10 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
             const int o = (G::K & 1) ? (par ? o1 : o0) : o0;
             den = fmaf(s1[idx + o], kc.k[i], den);
         }
-        if (border) {
+        if (border && !DE_X_NOBORDER_EVAL) {
             const int gxu = bx0 + (((ul - G::HU) * G::K) >> 1) + vl - G::HV, gyu = by0 + ul - G::HU;
             if (gxu < 0 || gxu > xmax || gyu < 0 || gyu > ymax)
-                den = de_b2_global<P>(N, d, de_clampi(gxu, 0, xmax), de_clampi(gyu, 0, ymax), kc);
+                den = sF2[gxu < 0 ? ul : gxu > xmax ? G::ROWS + ul : 2 * G::ROWS + (gyu < 0 ? 0 : G::XS) + gxu - (bx0 - G::HV + G::SHMIN)];
         }
         const float ra = frcp(den + 1.0e-6f) * gspeed;
         const float4 n = sA[idx - G::AOFF];
@@ -918,6 +997,12 @@ taps:
     {
         int cu, cv;
         de_out_px<P>(wv, G::OPT > 1 ? de_lane_here() : (tid & 63), cu, cv);
+        // The parallelogram sticks out of the image at both ends of a band (and the last row of tiles below it): a wave none of whose
+        // outputs lies inside has helped to stage the tile and is done — 4.5 % of the waves at 1080p (round 5).
+        {
+            const int xq = bx0 + ((cu * G::K) >> 1) + cv, yq = by0 + cu;
+            if (DE_SKIP_OUTSIDE && __builtin_amdgcn_ballot_w64(xq >= 0 && xq <= xmax && yq <= ymax) == 0ull) continue;
+        }
         // a wave with a dead centre (w_c = 0: the rim of the flame, sparse images) takes the form that handles one
         const bool slow = __builtin_amdgcn_ballot_w64(!(sA[(cu + G::HA) * G::COLS + cv + G::HV].w > 0.0f)) != 0ull;
         if ((G::K & 1) && (wv & 1)) { if (slow) de_tap_loop_slow<P, 1>(sA, sB, wv, cs2, spk, res); else de_tap_loop<P, 1, false>(sA, sB, wv, cs2, spk, res); }
@@ -992,8 +1077,10 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
     const uint32_t tiles_x = (d.astride + G::SPAN + G::TW - 1) / G::TW, tiles_y = (d.ah + G::TH - 1) / G::TH;
     const uint32_t ntiles = tiles_x * tiles_y;
     const uint32_t gran = tail.order == 2 ? 8u * DE_RUN : 8u;      // whole runs on every XCD
+    const uint32_t divisor = tail.order == 0 ? tiles_y : tiles_x, magic = (uint32_t)(0x100000000ull / divisor) + 1u;
+    if ((unsigned long long)(ntiles + gran) * divisor >= 0x100000000ull) abort();      // __umulhi(n, magic) is n / divisor for n * divisor < 2^32
     hipLaunchKernelGGL((k_de_dir<P, IN, OUT>), dim3(gran * ((ntiles + gran - 1) / gran)), dim3(G::NT), de_lds_for_residency(G::LDS, G::NT, ntiles, P), st, d, Nout, N, kc, spk,
-                       cs2, ads, dpow, gspeed, tiles_y, ntiles, tail);
+                       cs2, ads, dpow, gspeed, tiles_y, ntiles, tiles_x, magic, tail);
 }
 
 // in_mode (pattern 0 only): 0 = N holds the normalised image, 1 = the raw accumulator, 2 = the raw YUV
