@@ -19,6 +19,7 @@
 // "Round 3 (second half)" has the measurements behind every piece of this).
 #include "flame_device.h"
 #include "kernels.h"
+#include <cstdlib>
 
 __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restrict__ out4)
 {
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024, TWL == 7u ? 8 
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
               uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
-              uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap, uint32_t big_thr)
+              uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap, uint32_t big_thr, uint32_t gang, uint32_t nbins)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
@@ -146,7 +147,16 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     uint32_t *mk = reinterpret_cast<uint32_t *>(smem + rows_cap * FL_PAL_W * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
     u64 *tile = reinterpret_cast<u64 *>(smem + rows_cap * FL_PAL_W * 8 + blockDim.x * 4);       // [CELLS]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
-    const uint32_t bin = blockIdx.x / nparts, part = blockIdx.x % nparts;
+    // Workgroup -> (tile, part).  gang = 0: parts of a tile are consecutive workgroups.  gang = G (round 5 experiment, FLAME_BIN_GANG):
+    // G adjacent tiles with the SAME part are G consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8) — they start
+    // together on one L2 and walk the same batches, whose sorted records put adjacent tiles' runs into the same cache lines.
+    uint32_t bin, part;
+    if (gang == 0u) { bin = blockIdx.x / nparts; part = blockIdx.x % nparts; }
+    else {
+        const uint32_t loc = blockIdx.x >> 3, gq = (loc / gang) * 8u + (blockIdx.x & 7u);
+        bin = (gq / nparts) * gang + loc % gang; part = gq % nparts;
+        if (bin >= nbins) return;
+    }
     const uint32_t tx = bin % tiles_x, ty = bin / tiles_x;
 #ifdef ACC_X_TIMES
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
@@ -439,8 +449,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                     // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
                     // most `nparts` adds per launch (one per workgroup of its tile) onto a flushed cell,
                     // so chunks below big_thr = 1024/nparts hits are safe; larger ones go straight to the floats.
-                    // (When the flush waits for the frame's last launch a cell may start a launch with up to
-                    // 255 + big_thr - 1 hits — whoever finds 256 or more drains it —: big_thr = 768 / (nparts + 1).)
+                    // (Round 4's FLAME_FLUSH_LAST — one flush per frame instead of one per launch, for the on-die log experiment —
+                    // sized this threshold for a drain at 256 hits while cells drain at 512 (`full` below): removed in round 5.)
                     if ((uint32_t)(v >> 54) >= big_thr) big |= 1u << k;
                     else                                         // (as asm: the compiler waits for every returning atomic at the end of its branch)
                         asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "+v"(old[k]) : "v"(atom + py * astride + px), "v"(v) : "memory");
@@ -476,26 +486,39 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
                         u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
-                        uint32_t astride, uint32_t aheight, bool wide, bool flushed)
+                        uint32_t astride, uint32_t aheight, bool wide)
 {
-    const uint32_t big_thr = flushed ? 1024u / nparts : 768u / (nparts + 1u);
+    // k_flush has emptied every packed cell before this launch, and a cell receives at most one add per workgroup of its tile:
+    // chunks below 1024 / nparts hits cannot carry the 10-bit count past 1023 (larger ones go straight to the floats)
+    const uint32_t big_thr = 1024u / nparts;
     // LDS: the tile, 64 marks per wave, and as many palette rows (2 KB each) as the slot range of one
     // workgroup touches — capped by what lets two narrow workgroups (one wide) share a CU's 160 KB
     const uint32_t spr = nslots / FL_PAL_H, slots_per_part = (nslots + nparts - 1) / nparts;
     if (batch_records > 65536u) abort();        // directory words hold 16-bit counts; the kernel's marks 24 bits of 64 * batch_records
     const uint32_t want = (slots_per_part + spr - 1) / spr + 1;
+    // Gangs of 32 adjacent tiles for images of more than 512 tiles (round 5, profiles/r05_bin_gang.txt).  A batch's records are sorted
+    // by tile, so the runs of adjacent tiles share cache lines — at 4K / 8K a run is 8-14 records, a quarter to a half of a line — and
+    // with the parts of ONE tile as consecutive workgroups the tiles that share a line passed it at different times, each on whatever
+    // XCD its workgroup had landed on: k_accum_tiles fetched 14.5 GB per 8K launch for 4.3 GB of records (3.8 / 1.1 at 4K).  Ganged:
+    // 7.0 GB (1.8), 2504 -> 2304 us per launch at 8K, 627 -> 531 at 4K.  At 1080p (288 tiles, runs of 14 records, 16 parts) the gangs
+    // change nothing (347 -> 355 us): off.  FLAME_BIN_GANG forces a gang size (0: off).
+    static const int gang_env = getenv("FLAME_BIN_GANG") ? atoi(getenv("FLAME_BIN_GANG")) : -1;
+    const uint32_t gang = gang_env >= 0 ? (uint32_t)gang_env : (nbins > 512u ? 32u : 0u);
+    // gangs = ceil(nbins / gang) * nparts, dealt to the XCDs eight at a time
+    const uint32_t ngangs = gang ? ((nbins + gang - 1) / gang) * nparts : 0u;
+    const uint32_t grid = gang ? ((ngangs + 7u) / 8u) * 8u * gang : nbins * nparts;
     if (wide) {
         const uint32_t rows = want < 2u ? 2u : want > 12u ? 12u : want;
         static unsigned long long attr = 0;
         ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, attr);
-        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(nbins * nparts), dim3(1024),
+        hipLaunchKernelGGL(k_accum_tiles<FL_TILE_W_WIDE_LOG2>, dim3(grid), dim3(1024),
                            (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4 + rows * FL_PAL_W * 8, st,
-                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr);
+                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr, gang, nbins);
         return;
     }
     const uint32_t rows = want < 2u ? 2u : want > (uint32_t)ACC_ROWS_MAX ? (uint32_t)ACC_ROWS_MAX : want;
     static unsigned long long attr = 0;
     ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
-    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(nbins * nparts), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
-                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr);
+    hipLaunchKernelGGL(k_accum_tiles<7u>, dim3(grid), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
+                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr, gang, nbins);
 }

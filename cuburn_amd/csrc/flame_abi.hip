@@ -90,7 +90,6 @@ struct fl_ctx {
     uint32_t *d_sort = nullptr; size_t sort_words = 0;     // radix sort scratch (grow-only): digit counts + chunk totals
     uint32_t bin_rounds = 16, bin_parts = 0;      // bin_parts 0: chosen per image (see do_iter_launch)
     uint32_t launch_rounds = 0;                   // FLAME_LAUNCH_ROUNDS: write-enabled rounds per binned launch (0: FL_BIN_MAX_ROUNDS) — the sample log of a launch is nslots x 256 x rounds x 4 bytes
-    bool env_flush_last = false;                  // FLAME_FLUSH_LAST=1: one k_flush at the end of the frame instead of one per launch
     uint32_t round_counter = 0;
     static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
@@ -262,7 +261,6 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 0;      // 3: de.hip's kernels, all queued when the tail is known; 4: overlapped launches
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
-    c->env_flush_last = env_on("FLAME_FLUSH_LAST");
     c->env_de_unfused_ends = env_on("FLAME_DE_UNFUSED_ENDS");   // separate normalise / un-normalise passes around the 8 directions
     c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
@@ -657,7 +655,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         uint32_t parts = c->bin_parts ? c->bin_parts : (wide ? 16384u : 8192u) / nbins;
         parts = parts < 1u ? 1u : parts > (c->bin_parts ? 64u : 16u) ? (c->bin_parts ? 64u : 16u) : parts;
         launch_accum_tiles(drain, L(c).d_log[buf], L(c).d_dir[buf], L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
-                           parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide, !c->env_flush_last);
+                           parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
         ev_end_on(e2, drain);
         HIPCHK(hipGetLastError());
     }
@@ -713,10 +711,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
         // the drains of launch k-2 read this log / directory set: they must be done before it is rewritten
         if (pipelined && k >= 2) HIPCHK(hipStreamWaitEvent(L(c).stream, L(c).ev_ac[buf], 0));
         if ((rc = do_iter_launch(c, g, d, (uint32_t)n + f, f, false, accum_mode, buf, drain))) return rc;
-        // (binned mode: the packed cells take the next launch's tile adds on top of this one's — a cell is drained by the
-        // add that finds it at 256 hits — so the flush may wait for the frame's last launch: FLAME_FLUSH_LAST)
-        if (!(c->env_flush_last && accum_mode == FL_ACCUM_BINNED && rounds > n))
-            if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED, drain))) return rc;
+        if ((rc = do_flush(c, d, accum_mode != FL_ACCUM_BINNED, drain))) return rc;
         if (pipelined) HIPCHK(hipEventRecord(L(c).ev_ac[buf], drain));
         rounds -= n;
         batch += batch / 2;

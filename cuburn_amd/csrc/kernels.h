@@ -56,7 +56,7 @@ void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t 
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,
                         u64 *atom, float *out4, uint32_t tiles_x, uint32_t nbins, uint32_t nparts,
                         uint32_t nbatch_total, uint32_t batch_records, uint32_t nslots,
-                        uint32_t astride, uint32_t aheight, bool wide, bool flushed = true);
+                        uint32_t astride, uint32_t aheight, bool wide);
 
 // interp.hip
 void launch_interp_palette(hipStream_t st, fl_mwc *rng_pal, const float *ptimes, const float4 *pals,

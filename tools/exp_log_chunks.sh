@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: FLAME_FLUSH_LAST, which this experiment ran with in round 4, no longer exists: one flush per launch)
 # Round 4: keep the sample log on die?  A frame's iterate / accumulate pair cut into launches of FLAME_LAUNCH_ROUNDS
 # write-enabled rounds (log chunk = nslots x 256 x rounds x 4 B: 1024 rounds = 1 GiB, 96 = 96 MB < the 256 MiB Infinity
 # Cache), launch k+1 iterating while launch k is accumulated (two log sets), one flush at the end, log stores
@@ -6,7 +7,7 @@
 # usage: tools/exp_log_chunks.sh ["ROUNDS NT PARTS" ...]
 for S in "$@"; do
   set -- $S; R=$1; NT=$2; P=$3
-  env FLAME_LAUNCH_ROUNDS=$R FLAME_FLUSH_LAST=1 FLAME_RTC_FLAGS=-DFL_LOG_NT=$NT FLAME_BIN_PARTS=$P \
+  env FLAME_LAUNCH_ROUNDS=$R FLAME_RTC_FLAGS=-DFL_LOG_NT=$NT FLAME_BIN_PARTS=$P \
     python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 --preheat-seconds 1.5 --min-timed-frames 100 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_frame']; r=d['roofline']
