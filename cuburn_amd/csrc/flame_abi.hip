@@ -652,7 +652,9 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         // no more — every workgroup zeroes and drains a whole LDS tile whatever its share of records
         // (256x64 tiles, one workgroup per CU: twice as many — a dense region then spreads over more
         // workgroups; cfg5 8K: 3 per tile 20.7 ms of accumulate per frame, 8 per tile 16.2, 12: 18.2)
-        uint32_t parts = c->bin_parts ? c->bin_parts : (wide ? 16384u : 8192u) / nbins;
+        // (round 5: with the ganged tile order of images of more than 512 tiles — launch_accum_tiles — six per tile at 4K and 8K:
+        // 507 / 531 / 619 us per 4K launch with 6 / 8 / 12, 2187 / 2410 / 2677 at 8K; profiles/r05_bin_parts.txt)
+        uint32_t parts = c->bin_parts ? c->bin_parts : nbins > 512u ? ((wide ? 12800u : 6400u) + nbins / 2u) / nbins : (wide ? 16384u : 8192u) / nbins;
         parts = parts < 1u ? 1u : parts > (c->bin_parts ? 64u : 16u) ? (c->bin_parts ? 64u : 16u) : parts;
         launch_accum_tiles(drain, L(c).d_log[buf], L(c).d_dir[buf], L(c).d_palette, L(c).d_atom, (float *)L(c).d_front, tiles_x, nbins,
                            parts, nbatch_total, c->bin_rounds * (uint32_t)c->nw * 64, c->nslots, d.astride, d.ah, wide);
