@@ -374,6 +374,25 @@ def main():
                 de_traffic = int(kb('k_de_')) or None
         except Exception:
             traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
+        # Instruction-mix notes come from counter files committed under profiles/ (tools/pmc_sq.sh, tools/de_slot_budget.sh), never
+        # from literals here: the newest file measured on THIS config, named in the note, or no numbers at all.
+        def newest_profile(pattern):
+            import glob
+            found = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)))
+            return found[-1] if found else None
+        sq_file = newest_profile('r0*_sq_counters_k_iter_spec.json' if args.config == 'cfg2' else 'r0*_%s_sq_counters_k_iter_spec.json' % args.config)
+        if sq_file:
+            sq = json.load(open(sq_file))
+            iter_bound = ('instruction issue across the vector, scalar and branch units (DESIGN 4.1): %.0f M vector + %.0f M scalar instructions + %.0f M branches '
+                          'per launch, SQ counters of %s measured on %s (%s)'
+                          % (sq.get('SQ_INSTS_VALU', 0) / 1e6, sq.get('SQ_INSTS_SALU', 0) / 1e6, sq.get('SQ_INSTS_BRANCH', 0) / 1e6,
+                             'k_iter_spec', args.config, os.path.basename(sq_file)))
+        else:
+            iter_bound = 'no SQ counter file for %s under profiles/ (tools/pmc_sq.sh)' % args.config
+        de_file = newest_profile('r0*_de_slot_budget.txt' if args.config == 'cfg2' else 'r0*_%s_de_slot_budget.txt' % args.config)
+        de_bound = ('vector-ALU issue slots: per-direction slot budget and the one rate that reproduces the kernels\' times, measured on %s, in %s; '
+                    '512 B/px is the algorithmic byte count of the reference pass structure' % (args.config, os.path.basename(de_file))) if de_file else \
+                   ('no slot budget measured on %s under profiles/ (tools/de_slot_budget.sh); 512 B/px is the algorithmic byte count of the reference pass structure' % args.config)
         launches = max(acc['launches'], 1)
         big_ms = (acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps
         iter_launch_s = acc['iter_ms'] * 1e-3 / launches
@@ -416,7 +435,7 @@ def main():
                          'traffic_measured_in_this_run': False,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
-                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': 'instruction issue: 351 M vector + 160 M scalar instructions + 50 M branches per launch with four waves per SIMD to overlap them; not bandwidth, not the per-round barrier (DESIGN 4.1, round 4)',
+                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': iter_bound,
                                     'measured_bytes_per_launch': iter_bytes,
                                     'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
                                     'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
@@ -431,7 +450,7 @@ def main():
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
                           'frac_of_achievable_6300': round(de_gbs / HBM_ACHIEVABLE_GBS, 5),
                           'traffic': de_traffic,
-                          'bound': 'vector-ALU issue slots (DESIGN 4.3 round 4: SQ_ACTIVE_INST_VALU = 87-100 % of a direction\'s duration, ~80 % of the rate the tap loop\'s instruction mix runs at alone; 15 % of HBM): 512 B/px is the algorithmic byte count of the reference pass structure'},
+                          'bound': de_bound},
             'kernel_ms_per_frame': {'iter': round(acc['iter_ms'] / ksteps, 4), 'accum_flush': round(acc['flush_ms'] / ksteps, 4),
                                     'filters': round(acc['filter_ms'] / ksteps, 4), 'note': 'un-overlapped (single stream lane)'},
         }

@@ -37,6 +37,21 @@ def test_bench_single_gpu_line(built):
     assert 0 < out['roofline']['frac'] < 1 and out['roofline']['bound'] == 'hbm'
     assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['value'] > 0
     assert out['config']['samples_per_frame'] >= 2 ** 28
+    # counter-derived notes name the config they were measured on and the profiles/ file they come from (no literals in bench.py)
+    assert 'cfg2' in out['roofline']['k_iter']['bound'] and 'sq_counters_k_iter_spec.json' in out['roofline']['k_iter']['bound']
+    assert 'cfg2' in out['de_filter']['bound'] and 'de_slot_budget' in out['de_filter']['bound']
+
+
+def test_bench_counter_notes_belong_to_the_config(built):
+    """A cfg3 line must not carry cfg2's counters: its notes name cfg3 (and a cfg3 file) or say that nothing was measured."""
+    out = run_bench(['--gpus', '1', '--cpu-seconds', '0', '--config', 'cfg3', '--steps', '2', '--warmup', '1', '--min-timed-frames', '2',
+                     '--preheat-seconds', '0'])
+    for note in (out['roofline']['k_iter']['bound'], out['de_filter']['bound']):
+        assert 'cfg3' in note and 'cfg2' not in note
+    src = open(os.path.join(REPO, 'bench.py')).read()
+    import re
+    assert not re.search(r"\d+ M vector|\d+ M scalar|\d+ M branches", src)      # no literal counter values
+
 
 
 @pytest.mark.parametrize('shard', ['frames', 'samples'])
