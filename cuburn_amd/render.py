@@ -127,7 +127,11 @@ class Framebuffers(object):
         """The native context (re-created by set_dim when the image size asks for the other geometry)."""
         if self._ctx is None:
             lib = _lib.load()
-            seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, self.host_seed))
+            # The reference keeps its seed table for the manager's lifetime (cuburn/render.py:95-104).  Here a geometry switch
+            # re-creates the context and with it the RNG states: the generation count is mixed into the host seed, so that an
+            # animation whose samples per frame cross 2^28 does not replay the same streams after every switch.
+            seed = self.host_seed if not self.host_seed else (self.host_seed + 0x9E3779B1 * self.generation) & 0x7fffffff or 1
+            seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, seed))
             ctx = C.c_void_p()
             _lib.check(lib.fl_ctx_create(self.device, self.stream, seeds.ctypes.data, self.nwalkers,
                                          self.nslots, C.byref(ctx)))

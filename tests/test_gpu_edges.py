@@ -306,6 +306,19 @@ def test_walker_geometry_follows_image_size():
     assert (m.fb.nw, m.fb.nslots) == (4, 1024) and m.fb.generation == gen0 + 3
     a, a2 = np.array(a).astype(np.float64), np.array(a2).astype(np.float64)
     assert np.abs(a - a2).mean() < 6.0
+    # ... with RNG states of its own: the generation count is mixed into the seed (the reference's seed table lives as long as
+    # its manager, render.py:95-104; round 4 re-seeded every re-created context identically)
+    assert not np.array_equal(a, a2)
+    # 1024 <-> 1536 slots twice on one manager: the two 1024-slot frames, and the two 1536-slot frames, differ
+    many_m = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
+    rdr_m = render.Renderer(gnm, many_m)
+    flips = []
+    for gp, rd in ((many_m, rdr_m), (small, rdr_s), (many_m, rdr_m), (small, rdr_s)):
+        evt, f = m.queue_frame(rd, gnm, gp, 0.5); evt.synchronize()
+        flips.append(((m.fb.nw, m.fb.nslots), np.array(f)))
+    assert [g for g, _ in flips] == [(4, 1536), (4, 1024), (4, 1536), (4, 1024)]
+    assert not np.array_equal(flips[1][1], flips[3][1]) and not np.array_equal(flips[0][1], flips[2][1])
+    assert np.abs(flips[1][1].astype(np.float64) - flips[3][1]).mean() < 6.0
     # many samples per frame on a small image: the 1536-slot geometry the manager starts with stays
     q = render.RenderManager(device=0, host_seed=5)
     many = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
