@@ -59,20 +59,12 @@ struct Lane {
     hipEvent_t ev_iter_done = nullptr;     // walkers + their RNG states
     hipEvent_t ev_out_done = nullptr;      // output-dither RNG states
     bool interp_rec = false, iter_rec = false, out_rec = false;
-    // deferred ends of the filter chain (see flush_pending): a `yuv` that has not run yet, and a
-    // DE result that still sits normalised in `pend_N` (+ a logscale to apply while un-normalising)
+    // deferred ends of the filter chain (see flush_pending): a `yuv` that has not run yet, and the DE — all eight directions,
+    // the first normalising the accumulator (pend_in_mode: 1 raw, 2 raw YUV), the last un-normalising (+ a logscale to apply
+    // on the way, + a colorclip if that is the call that flushes it): run_de_finish
     bool pend_yuv = false, pend_finish = false, pend_log = false;
-    const float4 *pend_N = nullptr;
     float pend_k1 = 0.0f, pend_k2 = 0.0f;
-    // ... or, in the one-kernel-per-direction form, the LAST DIRECTION itself is still to run: it reads
-    // pend_N, un-normalises and tone-maps as it stores into d_front (de.hip, OUT = 1)
-    bool pend_last = false;
-    // the whole eight-direction DE pending as one persistent launch (de_chain.hip): 1 = persistent, 2 = its tiles one direction per launch
-    int pend_chain = 0, pend_in_mode = 0;
-    void *d_chain = nullptr; size_t chain_bytes = 0;      // the launch's parameter block, list heads and counters
-    // FLAME_DE_CHAIN=4: eight overlapped launches on `stream` and `aux` (idle while the filters run); the scratch's epoch and totals
-    hipEvent_t ev_de_fork = nullptr, ev_de_join = nullptr;
-    DeLapState lap = {};
+    int pend_in_mode = 0;
     float pend_dp[5] = {0, 0, 0, 0, 0}, pend_k7[7] = {0, 0, 0, 0, 0, 0, 0};
     fl_dim pend_dim = {0, 0, 0, 0, 0};
 };
@@ -95,16 +87,11 @@ struct fl_ctx {
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
     uint32_t frame_lane[kFrames] = {};
     uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
-    std::vector<EvPair> pool, iter_ev, accum_ev, flush_ev, filt_ev, de_ev, definish_ev;
+    std::vector<EvPair> pool, iter_ev, accum_ev, flush_ev, filt_ev, de_ev;
     size_t pool_used = 0;
     bool timing = true;
-    // environment switches, read once when the context is created
-    // FLAME_DE_CHAIN: how the DE's eight directions are launched.  3 (default): de.hip's eight kernels, queued together once the
-    // tone filters that ride along in the last one are known (back to back on the stream: the two-lane frame loop is 3 %
-    // faster than with seven of them queued by the bilateral call and the eighth two host calls later, profiles/r04_de_defer.txt);
-    // 0: that earlier form; 1: ONE persistent launch (de_chain.hip); 2: the persistent launch's tiles, one direction per launch
-    int env_de_chain = 3;
-    bool env_bin_wide = false, env_de_reference = false, env_de_split = false, env_no_intra = false, env_de_unfused_ends = false;
+    // environment switches, read once when the context is created (listed in include/flame_hip.h)
+    bool env_bin_wide = false, env_no_intra = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
     uint32_t n_spec_launch = 0, n_interp_launch = 0;      // iterate launches by kernel since fl_timings_reset (fl_launch_stats)
 };
@@ -144,6 +131,7 @@ static const size_t kMaxTimed = 8192;
 static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
 {
     if (!c->timing || c->pool_used >= kMaxTimed) return nullptr;
+    if (c->pool.capacity() < kMaxTimed) c->pool.reserve(kMaxTimed);      // pointers into the pool are held across nested pairs: never reallocate
     if (c->pool_used == c->pool.size()) {
         EvPair p;
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
@@ -158,6 +146,7 @@ static EvPair *ev_begin(fl_ctx *c, std::vector<EvPair> &list)
 static EvPair *ev_pair(fl_ctx *c, std::vector<EvPair> &list)
 {
     if (!c->timing || c->pool_used >= kMaxTimed) return nullptr;
+    if (c->pool.capacity() < kMaxTimed) c->pool.reserve(kMaxTimed);
     if (c->pool_used == c->pool.size()) {
         EvPair p;
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
@@ -197,9 +186,7 @@ static void free_fb(fl_ctx *c)
     hipFree(L(c).d_atom); hipFree(L(c).d_hot); hipFree(L(c).d_outpix);
     L(c).d_front = L(c).d_back = L(c).d_side = nullptr; L(c).d_blur = nullptr; L(c).d_atom = nullptr;
     L(c).d_hot = nullptr; L(c).d_outpix = nullptr; L(c).nbins = 0; L(c).outpix_bytes = 0;
-    L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = L(c).pend_last = false;      // whatever was deferred dies with the buffers
-    L(c).pend_chain = 0;
-    L(c).pend_N = nullptr;
+    L(c).pend_yuv = L(c).pend_finish = L(c).pend_log = false;      // whatever was deferred dies with the buffers
 }
 
 // cuburn/render.py:121-161 Framebuffers.alloc / set_dim: grow-only; on OOM free everything
@@ -256,13 +243,9 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
-    c->env_de_reference = env_on("FLAME_DE_REFERENCE_FORM");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
-    if (const char *e = getenv("FLAME_DE_CHAIN")) c->env_de_chain = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 0;      // 3: de.hip's kernels, all queued when the tail is known; 4: overlapped launches
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
     if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
-    c->env_de_unfused_ends = env_on("FLAME_DE_UNFUSED_ENDS");   // separate normalise / un-normalise passes around the 8 directions
-    c->env_de_split = env_on("FLAME_DE_SPLIT");      // previous form: blur kernel + packed-math bilateral kernel per direction
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
     // every failure below leaves through fl_ctx_destroy, which frees whatever exists so far
@@ -323,15 +306,13 @@ void fl_ctx_destroy(fl_ctx *c)
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
-        hipFree(ln.d_params); hipFree(ln.d_palette); hipFree(ln.d_chain);
+        hipFree(ln.d_params); hipFree(ln.d_palette);
         for (int k = 0; k < 2; ++k) {
             hipFree(ln.d_log[k]); hipFree(ln.d_dir[k]);
             if (ln.ev_it[k]) hipEventDestroy(ln.ev_it[k]);
             if (ln.ev_ac[k]) hipEventDestroy(ln.ev_ac[k]);
         }
         if (ln.aux) hipStreamDestroy(ln.aux);
-        if (ln.ev_de_fork) hipEventDestroy(ln.ev_de_fork);
-        if (ln.ev_de_join) hipEventDestroy(ln.ev_de_join);
         if (ln.ev_interp_done) hipEventDestroy(ln.ev_interp_done);
         if (ln.ev_iter_done) hipEventDestroy(ln.ev_iter_done);
         if (ln.ev_out_done) hipEventDestroy(ln.ev_out_done);
@@ -749,36 +730,20 @@ static void gauss7(float stdev, float *c)      // cuburn/filters.py:11-16
 static void run_de_finish(fl_ctx *c, const float *clip)
 {
     Lane &ln = L(c);
-    if (ln.pend_chain) {
-        // every direction in one persistent launch: the accumulator in d_front goes through d_back and ends in d_front
-        DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
-                    clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
-        if (ln.pend_chain == 3) {      // the eight per-direction kernels of de.hip, all queued here (the tail is known now)
-            float4 *Na = ln.d_back, *Nb = ln.d_front;
-            launch_de_dir(ln.stream, ln.pend_dim, 0, Na, Nb, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, nullptr);
-            for (int pat = 1; pat < 7; ++pat) {
-                launch_de_dir(ln.stream, ln.pend_dim, pat, Nb, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4]);
-                std::swap(Na, Nb);
-            }
-            launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], 0, &t);
-        } else if (ln.pend_chain == 4)
-            launch_de_lap(ln.stream, ln.aux, ln.ev_de_fork, ln.ev_de_join, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1],
-                          ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, &ln.lap);
-        else
-        launch_de_chain(ln.stream, ln.pend_dim, ln.d_front, ln.d_back, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
-                        ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, &t, ln.d_chain, ln.pend_chain == 2);
-        ln.pend_finish = ln.pend_log = ln.pend_last = false;
-        ln.pend_chain = 0;
-        return;
+    // the eight per-direction kernels of de.hip, all queued here (the tail is known now): the accumulator in d_front goes through
+    // d_back and ends in d_front
+    DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
+                clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
+    EvPair *e = ev_begin(c, c->de_ev);                               // the DE proper: fl_timings_detail[4], whoever flushes it
+    float4 *Na = ln.d_back, *Nb = ln.d_front;
+    launch_de_dir(ln.stream, ln.pend_dim, 0, Na, Nb, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], ln.pend_in_mode, nullptr);
+    for (int pat = 1; pat < 7; ++pat) {
+        launch_de_dir(ln.stream, ln.pend_dim, pat, Nb, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4]);
+        std::swap(Na, Nb);
     }
-    if (ln.pend_last) {
-        DeTail t = {ln.pend_log ? 1 : 0, ln.pend_k1, ln.pend_k2, clip ? 1 : 0, clip ? clip[0] : 0.f, clip ? clip[1] : 0.f,
-                    clip ? clip[2] : 0.f, clip ? clip[3] : 0.f, clip ? clip[4] : 0.f};
-        launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, ln.pend_N, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2],
-                      ln.pend_dp[3], ln.pend_dp[4], 0, &t);
-    } else
-        launch_de_finish_tone(ln.stream, ln.pend_dim, ln.d_front, ln.pend_N, ln.pend_log, ln.pend_k1, ln.pend_k2, clip != nullptr, clip);
-    ln.pend_finish = ln.pend_log = ln.pend_last = false;
+    launch_de_dir(ln.stream, ln.pend_dim, 7, ln.d_front, Na, ln.pend_k7, ln.pend_dp[0], ln.pend_dp[1], ln.pend_dp[2], ln.pend_dp[3], ln.pend_dp[4], 0, &t);
+    ev_end(c, e);
+    ln.pend_finish = ln.pend_log = false;
 }
 
 static void flush_pending(fl_ctx *c)
@@ -801,7 +766,6 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     if (rc) return rc;
     hipStream_t st = L(c).stream;
     float k7[7];
-    bool ran_finish = false;
     EvPair *e = ev_begin(c, c->filt_ev);
     switch (id) {
     case FL_FILT_YUV:
@@ -811,85 +775,15 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
     case FL_FILT_BILATERAL: {            // cuburn/filters.py:62-95
         REQUIRE(np >= 5, "bilateral needs sstd,cstd,dstd,dpow,gspeed");
         gauss7(1.0f, k7);
-        if (L(c).pend_finish || c->env_de_reference) flush_pending(c);
-        if (c->env_de_reference) {         // the literal per-tap form of the reference kernel
-            for (int pat = 0; pat < 8; ++pat) {
-                launch_den_blur(st, d, L(c).d_blur, L(c).d_front, pat, 0, k7);
-                launch_den_blur_1c(st, d, (float *)L(c).d_side, L(c).d_blur, pat, 1, k7);
-                launch_bilateral(st, d, L(c).d_back, L(c).d_front, (const float *)L(c).d_side, pat, 15, p[0], p[1], p[2], p[3], p[4]);
-                std::swap(L(c).d_front, L(c).d_back);
-            }
-            break;
-        }
-        if (!c->env_de_split && c->env_de_chain && !c->env_de_unfused_ends) {
-            // All eight directions in ONE persistent launch (de_chain.hip), deferred as a whole so that a following
-            // logscale / colorclip can ride along in the last direction's tiles
-            const size_t need = c->env_de_chain == 3 ? 0 : c->env_de_chain == 4 ? de_lap_scratch_bytes(d) : de_chain_scratch_bytes(d);
-            if (L(c).chain_bytes < need) {
-                if (L(c).d_chain) { sync_all(c); (void)hipFree(L(c).d_chain); L(c).d_chain = nullptr; L(c).chain_bytes = 0; }
-                HIPCHK(hipMalloc(&L(c).d_chain, need));
-                L(c).chain_bytes = need;
-                if (c->env_de_chain == 4) {      // flags, started-workgroup totals and the epoch start from zero together
-                    HIPCHK(hipMemsetAsync(L(c).d_chain, 0, need, st));
-                    L(c).lap = DeLapState{};
-                }
-            }
-            if (c->env_de_chain == 4 && !L(c).ev_de_fork) {
-                HIPCHK(hipEventCreateWithFlags(&L(c).ev_de_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&L(c).ev_de_join, hipEventDisableTiming));
-            }
-            L(c).pend_chain = c->env_de_chain; L(c).pend_in_mode = L(c).pend_yuv ? 2 : 1;
-            L(c).pend_yuv = false;
-            L(c).pend_finish = true; L(c).pend_last = false; L(c).pend_log = false; L(c).pend_N = L(c).d_front; L(c).pend_dim = d;
-            for (int i = 0; i < 5; ++i) L(c).pend_dp[i] = p[i];
-            for (int i = 0; i < 7; ++i) L(c).pend_k7[i] = k7[i];
-            break;
-        }
-        if (!c->env_de_split) {
-            // One kernel per direction (de.hip): N ping-pongs between the back and front buffers
-            float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-            if (c->env_de_unfused_ends) {      // separate normalising / un-normalising passes (the form the fused ends are tested against)
-                launch_de_normalise(st, d, Na, L(c).d_front, L(c).pend_yuv);
-                L(c).pend_yuv = false;
-                for (int pat = 0; pat < 8; ++pat) {
-                    launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
-                    std::swap(Na, Nb);
-                }
-                L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
-                break;
-            }
-            // The first direction normalises the accumulator (after `yuv`, if that is pending) as it stages
-            // it: front -> back; directions 1..6 ping-pong; the last one (back -> front) is left pending
-            // so that it can un-normalise and take a following logscale / colorclip with it.
-            launch_de_dir(st, d, 0, Na, Nb, k7, p[0], p[1], p[2], p[3], p[4], L(c).pend_yuv ? 2 : 1, nullptr);
-            L(c).pend_yuv = false;
-            for (int pat = 1; pat < 7; ++pat) {
-                launch_de_dir(st, d, pat, Nb, Na, k7, p[0], p[1], p[2], p[3], p[4]);
-                std::swap(Na, Nb);
-            }
-            // six swaps: the image sits in Na == d_back again
-            L(c).pend_finish = L(c).pend_last = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
-            for (int i = 0; i < 5; ++i) L(c).pend_dp[i] = p[i];
-            for (int i = 0; i < 7; ++i) L(c).pend_k7[i] = k7[i];
-            break;
-        }
-        {
-            // previous form (FLAME_DE_SPLIT=1): packed planes PR = (w^dpow, 1/(avg+1e-6)), ping-pong in the side buffer
-            const size_t nb2 = (size_t)d.ah * d.astride;
-            float *PRa = (float *)L(c).d_side, *PRb = PRa + 2 * nb2;
-            float4 *Na = L(c).d_back, *Nb = L(c).d_front;
-            // density plane W: written by the prep / bilateral passes, read by the next blur pass
-            if (L(c).pend_yuv) { launch_yuv_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]); L(c).pend_yuv = false; }
-            else launch_de_prep2(st, d, Na, PRa, L(c).d_blur, L(c).d_front, p[3]);
-            for (int pat = 0; pat < 8; ++pat) {
-                launch_den_blur2_lds(st, d, pat, PRa, L(c).d_blur, k7);
-                launch_de_bilateral_lds(st, d, pat, Nb, PRb, L(c).d_blur, Na, PRa, p[0], p[1], p[2], p[3], p[4]);
-                std::swap(Na, Nb); std::swap(PRa, PRb);
-            }
-            // 8 swaps: the result sits normalised in Na == d_back; un-normalising it into d_front
-            // is left pending so that a logscale / colorclip that follows can ride along
-            L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_N = Na; L(c).pend_dim = d;
-        }
+        if (L(c).pend_finish) flush_pending(c);
+        // One kernel per direction (de.hip), all eight deferred: the first normalises the accumulator as it stages it (after
+        // `yuv`, if that is pending), the last un-normalises and takes a following logscale / colorclip with it — queued
+        // together by run_de_finish once the tail is known (or when anything else looks at the buffers)
+        L(c).pend_in_mode = L(c).pend_yuv ? 2 : 1;
+        L(c).pend_yuv = false;
+        L(c).pend_finish = true; L(c).pend_log = false; L(c).pend_dim = d;
+        for (int i = 0; i < 5; ++i) L(c).pend_dp[i] = p[i];
+        for (int i = 0; i < 7; ++i) L(c).pend_k7[i] = k7[i];
     } break;
     case FL_FILT_LOGSCALE:
         REQUIRE(np >= 2, "logscale needs k1,k2");
@@ -901,7 +795,6 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         REQUIRE(np >= 5, "colorclip needs vib,highpow,gam,lin,lingam");
         if (L(c).pend_finish && !L(c).pend_yuv) {
             run_de_finish(c, p);
-            ran_finish = true;
             break;
         }
         flush_pending(c);
@@ -942,8 +835,6 @@ int fl_filter(fl_ctx *c, int id, uint32_t w, uint32_t h, const float *p, uint32_
         return fail(FL_E_UNSUPPORTED, "unknown filter id", __FILE__, __LINE__);
     }
     ev_end(c, e);
-    if (e && id == FL_FILT_BILATERAL) c->de_ev.push_back(*e);                 // normalise + 8 directions
-    if (e && ran_finish) c->definish_ev.push_back(*e);                        // un-normalise (+ logscale + colorclip riding along)
     HIPCHK(hipGetLastError());
     return FL_OK;
 }
@@ -1051,7 +942,7 @@ int fl_timings_reset(fl_ctx *c)
 {
     REQUIRE(c, "null ctx");
     sync_all(c);
-    c->iter_ev.clear(); c->accum_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->de_ev.clear(); c->definish_ev.clear(); c->pool_used = 0;
+    c->iter_ev.clear(); c->accum_ev.clear(); c->flush_ev.clear(); c->filt_ev.clear(); c->de_ev.clear(); c->pool_used = 0;
     c->n_spec_launch = c->n_interp_launch = 0;
     return FL_OK;
 }
@@ -1061,7 +952,7 @@ int fl_timings_detail(fl_ctx *c, float ms[6])
     REQUIRE(c && ms, "null argument");
     sync_all(c);
     ms[0] = sum_ms(c->iter_ev); ms[1] = sum_ms(c->accum_ev); ms[2] = sum_ms(c->flush_ev);
-    ms[3] = sum_ms(c->filt_ev); ms[4] = sum_ms(c->de_ev); ms[5] = sum_ms(c->definish_ev);
+    ms[3] = sum_ms(c->filt_ev); ms[4] = sum_ms(c->de_ev); ms[5] = 0.0f;      // [4]: the DE's eight launches (fused ends included), recorded where they are queued; [5]: unused since round 5
     return FL_OK;
 }
 
@@ -1246,15 +1137,6 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
     if (log && log_bytes) { snprintf(log, log_bytes, "%s", rc ? err.c_str() : "ok"); }
     if (rc) return fail(rtc_available() ? FL_E_HIP : FL_E_UNSUPPORTED, "per-genome kernel did not compile", __FILE__, __LINE__);
     return (int)(code.size() > 0 ? FL_OK : FL_E_HIP);
-}
-
-int fl_debug_de_chain_failed(fl_ctx *c)
-{
-    REQUIRE(c, "null ctx");
-    sync_all(c);
-    int bad = 0;
-    for (int i = 0; i < 2; ++i) if (c->lanes[i].d_chain && de_chain_failed(c->lanes[i].d_chain) != 0) bad = 1;
-    return bad;
 }
 
 int fl_debug_counters(fl_ctx *c, uint64_t out4[4])

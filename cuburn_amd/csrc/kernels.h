@@ -67,17 +67,8 @@ void launch_interp_params(hipStream_t st, float *params, const float *times, con
 
 // filters.hip
 void launch_yuv_to_rgb(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
-void launch_den_blur(hipStream_t st, fl_dim d, float *dst, const float4 *src, int pattern, int upsample, const float *coefs7);
 void launch_den_blur_1c(hipStream_t st, fl_dim d, float *dst, const float *src, int pattern, int upsample, const float *coefs7);
 void launch_full_blur(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, int pattern, int upsample, const float *coefs7);
-void launch_bilateral(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, const float *blur, int pattern,
-                      int radius, float sstd, float cstd, float dstd, float dpow, float gspeed);
-void launch_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
-void launch_yuv_de_prep2(hipStream_t st, fl_dim d, float4 *N, float *PR, float *W, const float4 *src, float dpow);
-void launch_de_finish_tone(hipStream_t st, fl_dim d, float4 *dst, const float4 *N, bool do_log, float k1, float k2, bool do_clip, const float *cc5);
-void launch_den_blur2_lds(hipStream_t st, fl_dim d, int pattern, float *PR, const float *W, const float *coefs7);
-void launch_de_bilateral_lds(hipStream_t st, fl_dim d, int pattern, float4 *Nout, float *PRout, float *Wout, const float4 *N, const float *PR,
-                             float sstd, float cstd, float dstd, float dpow, float gspeed);
 void launch_logscale(hipStream_t st, fl_dim d, float4 *buf, float k1, float k2);
 void launch_colorclip(hipStream_t st, fl_dim d, float4 *buf, float vib, float highpow, float gam, float lin, float lingam);
 void launch_gamma_full_hi(hipStream_t st, fl_dim d, float4 *dst, const float4 *src);
@@ -92,18 +83,9 @@ void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 struct DeTail { int do_log; float k1, k2; int do_clip; float vib, highpow, gam, lin, lingam; int order; };
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
                    float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 0, const DeTail *tail = nullptr);
-void launch_de_normalise(hipStream_t st, fl_dim d, float4 *N, const float4 *src, bool yuv);
-// de_chain.hip: all eight directions in one persistent launch (img0: input, in_mode as launch_de_dir's; the result lands
-// in img0; scratch: de_chain_scratch_bytes() of device memory); one_by_one: eight launches of the same tiles
-size_t de_chain_scratch_bytes(fl_dim d);
-void launch_de_chain(hipStream_t st, fl_dim d, float4 *img0, float4 *img1, const float *coefs7, float sstd, float cstd, float dstd,
-                     float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, bool one_by_one);
-int de_chain_failed(const void *scratch);
-// ... and as eight launches on two streams, each starting under the tail of the one before (FLAME_DE_CHAIN=4)
-struct DeLapState { uint32_t epoch; unsigned long long started[8]; };
-size_t de_lap_scratch_bytes(fl_dim d);
-void launch_de_lap(hipStream_t sa, hipStream_t sb, hipEvent_t fork, hipEvent_t join, fl_dim d, float4 *img0, float4 *img1, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail, void *scratch, DeLapState *state);
+// (pattern 0 normalises the raw accumulator as it stages it — in_mode 1, or 2: after yuv -> rgb —; pattern 7 un-normalises and
+// applies `tail`'s tone filters as it stores; round 5 removed the separate normalise / finish kernels, the persistent and the
+// overlapped eight-direction launches of round 4 (de_chain.hip: git history, commit 58f1875) and round 1's blur + packed-math pair)
 
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);

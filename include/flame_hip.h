@@ -242,8 +242,9 @@ void fl_host_free(void *p);
 int fl_timings_reset(fl_ctx *ctx);
 int fl_timings(fl_ctx *ctx, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *niter_launches);
 /* The same, split further: ms[0] iterate kernels, [1] tile accumulate, [2] flush, [3] all fl_filter calls,
- * [4] the DE proper (FL_FILT_BILATERAL: seven directions, the first normalising the accumulator), [5] the call that
- * un-normalised the DE result (the last direction, with logscale / colorclip riding along when they follow directly). */
+ * [4] the DE proper — the eight direction kernels, the first normalising the accumulator, the last un-normalising it with a
+ * following logscale / colorclip riding along — recorded around the launches themselves, whichever call flushes them
+ * (the colorclip that follows, another filter, fl_output, a debug tap); [5] unused since round 5 (always 0). */
 int fl_timings_detail(fl_ctx *ctx, float ms[6]);
 /* Which iterate kernel actually ran since the last fl_timings_reset: out[0] launches of the kernel compiled for the
  * genome's structure (hipRTC; the counterpart of the module the reference compiles per genome, cuburn/render.py:232-236),
@@ -292,9 +293,21 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
                          char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
 int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
-/* FLAME_DE_CHAIN=1 runs the eight DE directions (cuburn/filters.py:62-95) as one persistent launch whose tiles wait for
- * their neighbours of the previous direction; 1 if a wait of the launches so far ever gave up (a bug), else 0. */
-int fl_debug_de_chain_failed(fl_ctx *ctx);
+
+/* ---- run-time switches (environment; read when a context is created / a kernel is first launched) ----
+ * Every switch is an A/B lever of a documented measurement, none changes results beyond float summation order:
+ *   FLAME_LANES=1            one stream lane instead of two (kernel timing; profiles/ are taken with it)
+ *   FLAME_NO_INTRA_OVERLAP=1 the launches of a multi-launch frame strictly in series on one stream
+ *   FLAME_RTC=0              always the precompiled interpreter iterate kernel (no hipRTC per-genome kernel)
+ *   FLAME_RTC_FLAGS=...      extra options for the hipRTC compile; FLAME_RTC_DUMP=<dir> keeps its source / assembly
+ *   FLAME_BIN_ROUNDS=n       rounds per sorted batch of the sample log (default 16)
+ *   FLAME_BIN_PARTS=n        workgroups per tile of the tile accumulate (default: by image size)
+ *   FLAME_BIN_GANG=n         adjacent tiles per XCD gang of the tile accumulate (default 32 above 512 tiles, else 0 = off)
+ *   FLAME_BIN_WIDE=1         256x64 accumulate tiles for every image size
+ *   FLAME_LAUNCH_ROUNDS=n    write-enabled rounds per iterate launch (default 1024)
+ *   FLAME_DE_ORDER=d|dddddddd tile order of the DE kernels, one digit for all or one per direction (0 per-XCD column-major runs,
+ *                            1 row-major, 2 row-major in runs per XCD; default: by direction and image size, de.hip)
+ * Compile-time timing builds (-DDE_X_*, -DACC_X_*) produce wrong pictures and exist only in libraries built for tools/. */
 
 #ifdef __cplusplus
 }

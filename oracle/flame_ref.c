@@ -634,6 +634,15 @@ int ref_apply_xf(const int32_t *prog, const float *P, int xfi, float *px, float 
     return 0;
 }
 
+int ref_apply_xf_n(const int32_t *prog, const float *P, int xfi, uint32_t n, float *xyzw, ref_mwc *r)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = ref_apply_xf(prog, P, xfi, &xyzw[4 * i], &xyzw[4 * i + 1], &xyzw[4 * i + 2], &r[i]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 /* cuburn/code/iter.py:260-272: first xform whose cumulative density is >= the selector */
 static inline int select_xf(const int32_t *prog, const float *P, float sel)
 {
@@ -817,21 +826,20 @@ typedef struct f3_job {
     const ref_dim *dim; const int32_t *prog; const float *params; const float *palf;
     ref_mwc rng; uint64_t nsamples; int fuse; float *hist; uint64_t accepted; int tid; int nthreads; uint32_t nts;
     struct f3_job *all; pthread_barrier_t *bar; float *out4;
+    int nworkers;          /* OS threads: trajectory t is run by worker t % nworkers (jobs[0 .. nworkers) are the workers' own) */
 } f3_job;
 
-static void *f3_worker(void *arg)
+/* one trajectory (`j`: its RNG, its share of the chunks) into the histogram `hist` */
+static void f3_trajectory(f3_job *j, float *hist)
 {
-    f3_job *j = arg;
     const int32_t *prog = j->prog;
     int pstride = prog[3], nxf = prog[1], has_final = prog[2];
     const uint32_t astride = j->dim->astride, ah = j->dim->ah;
-    const size_t nfl = (size_t)ah * astride * 4;
-    j->hist = calloc(nfl, sizeof(float));          /* first touch on the worker's own NUMA node */
     ref_mwc *r = &j->rng;
     float x = ref_mwc_next_11(r), y = ref_mwc_next_11(r), c = ref_mwc_next_01(r);
     int fuse = j->fuse;
     /* The job's samples are cut into nchunks = nts * k chunks of (almost) equal length, chunk c
-     * belongs to temporal sample c % nts and to thread c % nthreads: every temporal sample gets the
+     * belongs to temporal sample c % nts and to trajectory c % nthreads: every temporal sample gets the
      * same number of iterations (cuburn/render.py:343-346: one block column per temporal sample). */
     const uint64_t total = j->nsamples;
     uint64_t per_ts = (total + 2048ull * j->nts) / (4096ull * j->nts);
@@ -855,16 +863,26 @@ static void *f3_worker(void *arg)
             if (ix >= astride || iy >= ah) continue;
             float cf = fmaf(fc, 255.0f, 0.49f * ref_mwc_next_11(r));
             int ci = (cf != cf) ? 0 : (cf >= 255.0f ? 255 : (cf <= 0.0f ? 0 : (int)rintf(cf)));
-            float *o = j->hist + 4 * ((size_t)iy * astride + ix);
+            float *o = hist + 4 * ((size_t)iy * astride + ix);
             o[0] += pal[3 * ci]; o[1] += pal[3 * ci + 1]; o[2] += pal[3 * ci + 2]; o[3] += 1.0f;
             j->accepted++;
         }
         fuse = 0;
     }
+}
+
+static void *f3_worker(void *arg)
+{
+    f3_job *j = arg;                               /* jobs[w], w < nworkers */
+    const size_t nfl = (size_t)j->dim->ah * j->dim->astride * 4;
+    j->hist = calloc(nfl, sizeof(float));          /* first touch on the worker's own NUMA node */
+    /* this worker's trajectories, one after the other, into its one histogram (tests ask for up to 65536 trajectories — a
+     * sample made like the GPU's, many short orbits; one OS thread and one image-sized histogram each was minutes of merging) */
+    for (int t = j->tid; t < j->nthreads; t += j->nworkers) f3_trajectory(&j->all[t], j->hist);
     /* merge: every worker sums one stripe of the image over all private histograms */
     pthread_barrier_wait(j->bar);
-    size_t lo = nfl * (size_t)j->tid / j->nthreads, hi = nfl * (size_t)(j->tid + 1) / j->nthreads;
-    for (int t = 0; t < j->nthreads; ++t) {
+    size_t lo = nfl * (size_t)j->tid / j->nworkers, hi = nfl * (size_t)(j->tid + 1) / j->nworkers;
+    for (int t = 0; t < j->nworkers; ++t) {
         const float *h = j->all[t].hist;
         for (size_t i = lo; i < hi; ++i) j->out4[i] += h[i];
     }
@@ -886,19 +904,22 @@ double ref_flam3_render(const ref_dim *dim, const int32_t *prog, const float *pa
         ref_unpack_cell(palette[i], u);
         palf[3 * i] = (float)u[0] * INV255; palf[3 * i + 1] = (float)u[1] * INV255; palf[3 * i + 2] = (float)u[2] * INV255;
     }
+    /* `nthreads` trajectories on at most 64 OS threads (up to 64 — the CPU baseline's case — one trajectory per OS thread) */
+    const int nworkers = nthreads < 64 ? nthreads : 64;
     f3_job *jobs = calloc(nthreads, sizeof(f3_job));
-    pthread_t *th = calloc(nthreads, sizeof(pthread_t));
+    pthread_t *th = calloc(nworkers, sizeof(pthread_t));
     pthread_barrier_t bar;
-    pthread_barrier_init(&bar, NULL, nthreads);
+    pthread_barrier_init(&bar, NULL, nworkers);
     for (int t = 0; t < nthreads; ++t) {
         jobs[t] = (f3_job){dim, prog, params, palf, seeds[t % nseeds], nsamples,
-                           fuse, NULL, 0, t, nthreads, nts, jobs, &bar, out4};
+                           fuse, NULL, 0, t, nthreads, nts, jobs, &bar, out4, nworkers};
     }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, f3_worker, &jobs[t]);
+    for (int t = 0; t < nworkers; ++t) pthread_create(&th[t], NULL, f3_worker, &jobs[t]);
     uint64_t acc = 0;
-    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); acc += jobs[t].accepted; }
+    for (int t = 0; t < nworkers; ++t) pthread_join(th[t], NULL);
+    for (int t = 0; t < nthreads; ++t) acc += jobs[t].accepted;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     pthread_barrier_destroy(&bar);
     free(jobs); free(th); free(palf);

@@ -50,6 +50,8 @@ void ref_interp_palette(const float *pal_rgba, const float *pal_times, uint32_t 
 
 /* cuburn/code/iter.py:121-149 + variations.py */
 int ref_apply_xf(const int32_t *prog, const float *P, int xfi, float *x, float *y, float *color, ref_mwc *r);
+/* ... for n points {x, y, color, unused} with one RNG state each, results in place (one call per variation test instead of one per point) */
+int ref_apply_xf_n(const int32_t *prog, const float *P, int xfi, uint32_t n, float *xyzw, ref_mwc *r);
 int ref_var_supported(int id);
 
 /* cuburn/code/iter.py:157-418 (device model, deterministic) */

@@ -306,7 +306,7 @@ def test_de_kernels_hold_32_waves_per_cu_without_scratch(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     kernels = re.split(r'Function Name: ', r.stderr)[1:]
     de = [k for k in kernels if k.startswith('_Z8k_de_dir')]
-    assert len(de) == 11                                   # 8 directions, 3 input forms of the first, 2 output forms of the last
+    assert len(de) == 9                                    # 8 directions, 2 input forms of the first (raw / raw YUV accumulator)
     for k in de:
         num = lambda key: int(re.search(key + r': (\d+)', k).group(1))
         assert num('VGPRs') <= 64 and num(r'ScratchSize \[bytes/lane\]') == 0 and num('TotalSGPRs') <= 80, k[:300]

@@ -728,15 +728,10 @@ def sparse_accum(dim, seed=3):
     return buf.reshape(-1, 4)
 
 
-@pytest.mark.parametrize('form', ['fused', 'split', 'reference'])
-def test_filter_bilateral_sparse(built, form, monkeypatch):
-    """Low-density input: every form of the DE chain stays finite and agrees with the oracle."""
-    monkeypatch.delenv('FLAME_DE_REFERENCE_FORM', raising=False)
-    monkeypatch.delenv('FLAME_DE_SPLIT', raising=False)
-    if form == 'split':          # blur kernel + packed-math bilateral kernel per direction (the round-1 form)
-        monkeypatch.setenv('FLAME_DE_SPLIT', '1')
-    if form == 'reference':
-        monkeypatch.setenv('FLAME_DE_REFERENCE_FORM', '1')
+def test_filter_bilateral_sparse(built):
+    """Low-density input: the DE chain stays finite and agrees with the oracle.  (Rounds 1-4 also ran the literal per-tap kernel
+    and round 1's blur + packed-math pair here; round 5 removed both from the library.)"""
+    form = 'one kernel per direction'
     m = render.RenderManager(device=0, nslots=NSLOTS, host_seed=7)
     dim = m.fb.calc_dim(FW, FH); d = O.calc_dim(FW, FH)
     buf = sparse_accum(dim)
@@ -1266,95 +1261,6 @@ def test_cfg2_full_size_iterate_and_filter_chain(built):
     m.fb.free()
 
 
-@pytest.mark.parametrize('size', [(200, 120), (640, 360), (1920, 1080)])
-def test_de_persistent_chain_equals_eight_launches(built, size, monkeypatch):
-    """FLAME_DE_CHAIN=1: the eight DE directions as ONE persistent launch (de_chain.hip) — every tile waits for the tiles of
-    the previous direction within its reach, written by other CUs of the same launch (write-through stores, L1-bypassing
-    loads, per-band counters).  Same bits as the same tiles run one direction per launch (FLAME_DE_CHAIN=2), for every
-    chain shape, several times over (a stale read or a tile that ran early shows as a different pixel), on a small
-    image (one work list), a mid-sized one and 1080p (one list per XCD, cross-stripe waits); and the same picture as
-    the default one-kernel-per-direction path, whose other tile shapes only move the border / interior choice of the
-    density blur's summation order."""
-    lib = _lib.load()
-    w, h = size
-    steps = {'yuv': [], 'bilateral': [6.0 * w / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
-             'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)]}
-    mgrs = {}
-    for mode in ('1', '2', '0', '4'):
-        monkeypatch.setenv('FLAME_DE_CHAIN', mode)
-        mgrs[mode] = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
-    dim = mgrs['1'].fb.calc_dim(w, h)
-    buf = synth_accum(dim, seed=3)
-
-    def run(m, chain):
-        _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
-        m.fb.write('front', buf)
-        for name in chain:
-            arr = np.asarray(steps[name], np.float32)
-            _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
-        return m.fb.read('front', buf.shape, np.float32)
-
-    for chain in (['yuv', 'bilateral', 'logscale', 'colorclip'], ['bilateral'], ['yuv', 'bilateral', 'logscale']):
-        one = run(mgrs['2'], chain)
-        assert np.isfinite(one).all() and one.max() > 0
-        for rep in range(4 if w < 1920 else 8):
-            per = run(mgrs['1'], chain)
-            assert np.array_equal(per.view(np.uint32), one.view(np.uint32)), (chain, rep, int((per != one).sum()))
-            # FLAME_DE_CHAIN=4: the same tiles as eight launches on two streams, each starting under the tail of the one before
-            lap = run(mgrs['4'], chain)
-            assert np.array_equal(lap.view(np.uint32), one.view(np.uint32)), ('overlapped', chain, rep, int((lap != one).sum()))
-        std = run(mgrs['0'], chain)
-        err = np.abs(std - one)
-        assert err.max() <= 2e-5 * max(1.0, float(np.abs(std).max())) and err.mean() < 1e-7 * max(1.0, float(np.abs(std).max())), (chain, err.max(), err.mean())
-    assert lib.fl_debug_de_chain_failed(mgrs['1'].fb.ctx) == 0 and lib.fl_debug_de_chain_failed(mgrs['4'].fb.ctx) == 0
-    for m in mgrs.values():
-        m.fb.free()
-
-
-def test_de_overlapped_launches_across_sizes(built, monkeypatch):
-    """FLAME_DE_CHAIN=4 clears nothing between chains (a tile's flag holds the epoch of the chain that finished it, the
-    started-workgroup counts only grow): alternate image sizes on one context, then frames in flight on both stream lanes,
-    every result equal to the same tiles run one direction per launch."""
-    lib = _lib.load()
-    monkeypatch.setenv('FLAME_DE_CHAIN', '4')
-    lap = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
-    monkeypatch.setenv('FLAME_DE_CHAIN', '2')
-    one = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
-    for rep, (w, h) in enumerate([(640, 360), (200, 120), (640, 360), (333, 217), (200, 120), (640, 360)]):
-        dim = lap.fb.calc_dim(w, h)
-        buf = synth_accum(dim, seed=5 + rep)
-        steps = [('yuv', []), ('bilateral', [6.0 * w / 1920., 0.05, 1.5, 0.8, 4.0]), ('logscale', [4.1875, 0.002])]
-        outs = []
-        for m in (lap, one):
-            _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
-            m.fb.write('front', buf)
-            for name, par in steps:
-                arr = np.asarray(par, np.float32)
-                _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
-            outs.append(m.fb.read('front', buf.shape, np.float32))
-        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (rep, w, h, int((outs[0] != outs[1]).sum()))
-    assert lib.fl_debug_de_chain_failed(lap.fb.ctx) == 0
-    # ... and through queue_frame: six frames, two in flight, alternating between the stream lanes (each lane has its own scratch, gates on its own
-    # second stream), same seeds -> the same pixels as the one-direction-per-launch form
-    gnm, prof = small(configs.cfg3, 640, 360, samples=2 ** 24)
-    gprof = profile.wrap(prof, gnm)
-    frames = {}
-    for name, m in (('lap', lap), ('one', one)):
-        rdr = render.Renderer(gnm, gprof)
-        frames[name] = []
-        prev = None
-        for k in range(7):                                   # frame k is queued before frame k - 1 is waited for
-            cur = m.queue_frame(rdr, gnm, gprof, 0.1 + 0.15 * k) if k < 6 else None
-            if prev is not None:
-                prev[0].synchronize()
-                frames[name].append(np.array(prev[1]))
-            prev = cur
-    for k in range(6):
-        assert np.array_equal(frames['lap'][k], frames['one'][k]), (k, int((frames['lap'][k] != frames['one'][k]).sum()))
-    assert lib.fl_debug_de_chain_failed(lap.fb.ctx) == 0
-    lap.fb.free(); one.fb.free()
-
-
 def test_deferred_filter_fusion_is_bit_identical(mgr):
     """fl_filter defers `yuv` and the DE's un-normalising pass so that bilateral / logscale /
     colorclip can take them along in one kernel.  Looking at the buffer between the calls forces
@@ -1383,29 +1289,3 @@ def test_deferred_filter_fusion_is_bit_identical(mgr):
         assert np.isfinite(a).all()
 
 
-def test_de_fused_ends_equal_separate_passes(mgr, monkeypatch):
-    """The first DE direction normalises the accumulator as it stages it and the last one
-    un-normalises / tone-maps as it stores (de.hip IN / OUT): same bits as the separate
-    k_de_normalise and k_de_finish_tone passes around eight plain directions (FLAME_DE_UNFUSED_ENDS=1)."""
-    lib = _lib.load()
-    dim = mgr.fb.calc_dim(FW, FH)
-    buf = synth_accum(dim)
-    steps = {'yuv': [], 'bilateral': [6.0 * FW / 1920., 0.05, 1.5, 0.8, 4.0], 'logscale': [4.1875, 0.002],
-             'colorclip': [1.0, -1.0, 0.25, 0.01, 0.01 ** (0.25 - 1)]}
-
-    def run(m, chain):
-        _lib.check(lib.fl_debug_clear(m.fb.ctx, dim.w, dim.h, 0))
-        m.fb.write('front', buf)
-        for name in chain:
-            arr = np.asarray(steps[name], np.float32)
-            _lib.check(lib.fl_filter(m.fb.ctx, _lib.FILT[name], dim.w, dim.h, arr.ctypes.data, len(arr)))
-        return m.fb.read('front', buf.shape, np.float32)
-
-    monkeypatch.setenv('FLAME_DE_UNFUSED_ENDS', '1')
-    sep = render.RenderManager(device=0, nslots=NSLOTS, host_seed=42)
-    for chain in (['yuv', 'bilateral', 'logscale', 'colorclip'], ['bilateral'], ['yuv', 'bilateral', 'logscale'],
-                  ['bilateral', 'colorclip']):
-        a, b = run(mgr, chain), run(sep, chain)
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), chain
-        assert np.isfinite(a).all() and a.max() > 0
-    sep.fb.free()

@@ -39,15 +39,5 @@ for k in [int(v) for v in sys.argv[1:]]:
     for lo, hi in ((0, 1e-12), (1e-12, 1e-6), (1e-6, 1e-3), (1e-3, 1e-1), (1e-1, 10), (10, 1e9)):
         sel = (w_ref >= lo) & (w_ref < hi)
         print('   oracle density in [%g, %g): %7d pixels, %6d off by > 2e-3 rel; of those input-empty: %d' % (lo, hi, sel.sum(), (sel & bad).sum(), (sel & bad & (b[..., 3] == 0)).sum()))
-    for form in ('FLAME_DE_REFERENCE_FORM', 'FLAME_DE_SPLIT'):
-        os.environ[form] = '1'
-        m2 = render.RenderManager(device=0, nslots=1024, host_seed=7)
-        m2.fb.set_dim(w, h)
-        _lib.check(lib.fl_debug_clear(m2.fb.ctx, dim.w, dim.h, 0))
-        m2.fb.write('front', buf)
-        _lib.check(lib.fl_filter(m2.fb.ctx, _lib.FILT['bilateral'], dim.w, dim.h, arr.ctypes.data, len(arr)))
-        dv2 = m2.fb.read('front', buf.shape, np.float32).reshape(dim.ah, dim.astride, 4)
-        with np.errstate(all='ignore'):
-            r2 = np.abs(dv2 - ref) / (np.abs(ref) + 1e-3)
-        print('   %s: values off by > 2e-3 rel: %d, worst %.3g; at the default form\'s worst pixel: %s' % (form, (r2 > 2e-3).sum(), np.nanmax(r2), dv2[iy, ix]))
-        del os.environ[form]; m2.fb.free()
+    # (round 5 ran the literal per-tap kernel and round 1's split form here as well — FLAME_DE_REFERENCE_FORM agreed with the oracle,
+    # FLAME_DE_SPLIT deviated exactly like the default form — before both were removed from the library)

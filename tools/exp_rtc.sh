@@ -5,6 +5,3 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_frame']
 print('$*: %.1f Ms/s  %.3f ms/frame  [iter %.3f accum %.3f filt %.3f]' % (d['value'], d['ms_per_step'], k['iter'], k['accum_flush'], k['filters']))"; }
 run FLAME_RTC=1 FLAME_LANES=2
 run FLAME_RTC=0 FLAME_LANES=2
-run FLAME_RTC=0 FLAME_LANES=2 FLAME_DE_SPLIT=1
-run FLAME_RTC=1 FLAME_LANES=2 FLAME_DE_SPLIT=1
-run FLAME_RTC=1 FLAME_LANES=1 FLAME_DE_SPLIT=1
