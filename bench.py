@@ -249,9 +249,19 @@ def main():
     dev = torch.device('cuda', local) if coll_dev == 'cuda' else torch.device('cpu')
     gather = D.FrameGather((h, w, 4), torch.uint8, dev, block=args.gather_block) if (world > 1 and args.shard == 'frames') else None
 
+    phase_ms = {}                                       # --shard samples: per-phase times of the band path, summed over frames
+    phase_evts = []
+
     def queue(slot):
         if args.shard == 'samples':
-            return D.queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=local)
+            evt, h_out = D.queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=local)
+            if hasattr(evt, 'phases'):
+                phase_evts.append(evt)
+                if len(phase_evts) > 64:                # resolved long ago: fold into the sums
+                    for k, v in phase_evts.pop(0).phases().items():
+                        phase_ms[k] = phase_ms.get(k, 0.0) + v
+                        phase_ms['_n_' + k] = phase_ms.get('_n_' + k, 0) + 1
+            return evt, h_out
         if slot is not None and slot.is_cuda:          # the frame goes straight into the tensor RCCL gathers
             return mgr.queue_frame(rdr, gnm, gprof, tc, dev_out=slot.data_ptr(), host=False)
         return mgr.queue_frame(rdr, gnm, gprof, tc)
@@ -261,7 +271,9 @@ def main():
             slot.copy_(torch.from_numpy(np.asarray(h_out)))
 
     def run(nframes):
-        D.run_frame_loop(queue, nframes, depth=1 if args.shard == 'samples' else args.depth, gather=gather, stage=stage)
+        # (sample-sharded frames are queued ahead like whole frames since round 5: nothing in queue_frame_sharded waits on the host,
+        # so frame k+1 iterates under frame k's exchange and filters)
+        D.run_frame_loop(queue, nframes, depth=args.depth, gather=gather, stage=stage)
 
     def fence():
         if world > 1:
@@ -345,6 +357,15 @@ def main():
         dist.all_reduce(ns)
         job_samples_per_step = int(ns.item())
 
+    sample_phases = None
+    if args.shard == 'samples' and phase_evts:
+        for e in phase_evts:
+            for k, v in e.phases().items():
+                phase_ms[k] = phase_ms.get(k, 0.0) + v
+                phase_ms['_n_' + k] = phase_ms.get('_n_' + k, 0) + 1
+        # milliseconds per frame on torch's stream of rank 0: up to the end of this rank's iterate + flush kernels, the
+        # reduce-scatter + halo exchange, the band's filters + conversion, the all-gather + the copy to the host
+        sample_phases = dict((k, round(v / phase_ms['_n_' + k], 4)) for k, v in phase_ms.items() if not k.startswith('_n_'))
     if rank == 0:
         dim = render.Framebuffers.calc_dim(w, h)
         nbins = dim.ah * dim.astride
@@ -428,7 +449,9 @@ def main():
                                               'of un-plotted iterations (render.py:215); value counts write-enabled samples only'},
                        'timed_frames': reps * args.steps,
                        'parallelism': ('frame-sharded x%d, RCCL gather of device frames, %d frames per collective' % (world, args.gather_block)
-                                       if args.shard == 'frames' else 'sample-sharded x%d, RCCL all-reduce of accumulators' % world)},
+                                       if args.shard == 'frames' else 'sample-sharded x%d: reduce-scatter by row bands + halo exchange, band-wise filters, all-gather of 8-bit rows '
+                                                                       '(all-reduce when the bands would be shorter than their halo)' % world),
+                       'sample_shard_phases_ms': sample_phases},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter + k_accum_tiles + k_flush (iterate chain: the 8-byte packed-cell RMW per sample)',
                          'achieved': round(chain, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(chain / HBM_PEAK_GBS, 5),
                          'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file else None,

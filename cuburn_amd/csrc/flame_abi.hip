@@ -90,6 +90,9 @@ struct fl_ctx {
     std::vector<EvPair> pool, iter_ev, accum_ev, flush_ev, filt_ev, de_ev;
     size_t pool_used = 0;
     bool timing = true;
+    static const uint32_t kDepEvents = 16;
+    hipEvent_t dep_ev[kDepEvents] = {};           // fl_stream_dependency
+    uint32_t dep_next = 0;
     // environment switches, read once when the context is created (listed in include/flame_hip.h)
     bool env_bin_wide = false, env_no_intra = false;
     bool use_rtc = true;                    // FLAME_RTC=0: always the interpreter kernel
@@ -298,6 +301,7 @@ void fl_ctx_destroy(fl_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    for (uint32_t i = 0; i < fl_ctx::kDepEvents; ++i) if (c->dep_ev[i]) hipEventDestroy(c->dep_ev[i]);
     for (int i = 0; i < 2; ++i) {
         if (c->lanes[i].stream) hipStreamSynchronize(c->lanes[i].stream);
         if (c->lanes[i].aux) hipStreamSynchronize(c->lanes[i].aux);
@@ -1014,6 +1018,33 @@ int fl_buffer_ptr(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size_t *nb
     int rc = buf_ptr(c, g, which, dev_ptr, nbytes);
     if (rc) return rc;
     sync_all(c);
+    return FL_OK;
+}
+
+int fl_buffer_ptr_async(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size_t *nbytes)
+{
+    REQUIRE(c && dev_ptr && nbytes, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    flush_pending(c);
+    return buf_ptr(c, g, which, dev_ptr, nbytes);
+}
+
+int fl_stream_dependency(fl_ctx *c, void *stream, int ctx_waits)
+{
+    REQUIRE(c, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t other = (hipStream_t)stream;
+    // a small ring of events: an event may be re-recorded once the wait that used it has been queued
+    hipEvent_t &ev = c->dep_ev[c->dep_next++ % fl_ctx::kDepEvents];
+    if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (ctx_waits) {
+        HIPCHK(hipEventRecord(ev, other));
+        HIPCHK(hipStreamWaitEvent(L(c).stream, ev, 0));
+    } else {
+        flush_pending(c);                                    // deferred filter steps belong to "everything queued so far"
+        HIPCHK(hipEventRecord(ev, L(c).stream));
+        HIPCHK(hipStreamWaitEvent(other, ev, 0));
+    }
     return FL_OK;
 }
 

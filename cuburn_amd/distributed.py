@@ -244,22 +244,35 @@ class _DeviceArray(object):
                                              data=(int(ptr), False), version=2)
 
 
-def accumulator_tensor(fb, device, dim=None):
+def accumulator_tensor(fb, device, dim=None, wait=True):
     """
     The float4 accumulator of the current frame as a flat float32 torch tensor.  The native
     buffers only ever grow, so their capacity depends on a rank's allocation history: with ``dim``
     the view covers exactly the frame's ah x astride cells, which is what every rank must hand to
-    the all-reduce.
+    the all-reduce.  ``wait=True`` blocks the host until the context's queued work is done (tests);
+    ``wait=False`` returns at once — order torch's stream behind the context's with ``order_streams``.
     """
     from . import _lib
     p, n = C.c_void_p(), C.c_size_t()
-    _lib.check(_lib.load().fl_buffer_ptr(fb.ctx, None, _lib.BUF['front'], C.byref(p), C.byref(n)))
+    fn = _lib.load().fl_buffer_ptr if wait else _lib.load().fl_buffer_ptr_async
+    _lib.check(fn(fb.ctx, None, _lib.BUF['front'], C.byref(p), C.byref(n)))
     nfloats = n.value // 4
     if dim is not None:
         want = int(dim.ah) * int(dim.astride) * 4
         assert want <= nfloats
         nfloats = want
     return torch.as_tensor(_DeviceArray(p.value, nfloats), device=torch.device('cuda', device))
+
+
+def order_streams(fb, device, ctx_waits):
+    """
+    Stream dependency between the native context's current lane and torch's current stream, no host wait
+    (fl_stream_dependency; the reference orders its two streams the same way, cuburn/render.py:358-364,419-430).
+    ``ctx_waits=False``: what torch queues next sees everything the context has queued; ``True``: the other way round.
+    """
+    from . import _lib
+    st = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(_lib.load().fl_stream_dependency(fb.ctx, C.c_void_p(st), 1 if ctx_waits else 0))
 
 
 # Rows of its input that one output row of a filter depends on, on either side (the reach of the chain is the sum
@@ -376,10 +389,12 @@ def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
     assert rows % 16 == 0 and rows >= 32 and band.shape[1] == dim.astride * 4
     bdim = Dimensions(dim.w, rows - 2 * mgr.fb.gutter, dim.aw, rows, dim.astride)
     assert mgr.fb.calc_dim(bdim.w, bdim.h) == bdim
-    _lib.check(_lib.load().fl_ctx_sync(mgr.fb.ctx))                 # whatever still uses the buffers
-    front = accumulator_tensor(mgr.fb, device, dim)
+    # torch's copy into the front buffer after whatever the lane still does with it, the filters after the copy: stream
+    # dependencies, no host wait (round 4 synchronised the host twice here)
+    order_streams(mgr.fb, device, ctx_waits=False)
+    front = accumulator_tensor(mgr.fb, device, dim, wait=False)
     front[:band.numel()].copy_(band.reshape(-1))
-    torch.cuda.synchronize(device)
+    order_streams(mgr.fb, device, ctx_waits=True)
     for filt in rdr.filts:
         params = getattr(gprof.filters, filt.name)
         filt._run(mgr.fb, bdim, filt.scalars(gprof, params, dim, tc))
@@ -388,48 +403,82 @@ def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
     out = torch.empty((bdim.h, bdim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=front.device)
     rdr.out.convert(mgr.fb, gprof, bdim)
     rdr.out.copy(mgr.fb, bdim, dev_out=out.data_ptr(), host=False)
+    order_streams(mgr.fb, device, ctx_waits=False)                  # torch reads `out` behind the conversion
     return out, bdim
 
 
 class TorchFrameEvent(object):
     """
     Completion handle of a frame whose last step ran on torch's stream (the band path's all-gather and D2H copy):
-    the interface of render.DurationEvent (cuburn/render.py:26-38) on a pair of torch events.  ``keep`` holds the
-    tensors the asynchronous copy still reads.
+    the interface of render.DurationEvent (cuburn/render.py:26-38) on torch events.  The frame's host buffer is
+    valid only after ``synchronize()`` (or a true ``query()``): the copy into it is asynchronous.  ``keep`` holds
+    the tensors that copy still reads; ``marks`` = [(name, event)] recorded along the way on torch's stream —
+    ``phases()`` gives the milliseconds between them (iterate / exchange / filter / gather).
     """
 
-    def __init__(self, start, end, keep=None):
-        self._start, self._end, self._keep, self._ms = start, end, keep, None
+    def __init__(self, marks, keep=None):
+        self._marks, self._keep, self._ms = marks, keep, None
 
     def synchronize(self):
         if self._ms is None:
-            self._end.synchronize()
-            self._ms = self._start.elapsed_time(self._end)
+            self._marks[-1][1].synchronize()
+            self._ms = self._marks[0][1].elapsed_time(self._marks[-1][1])
             self._keep = None
         return self
 
+    _finalise = synchronize          # Framebuffers._drop_ctx resolves outstanding handles before it destroys a context
+
     def query(self):
-        return self._ms is not None or self._end.query()
+        return self._ms is not None or self._marks[-1][1].query()
 
     def time(self):
         return self.synchronize()._ms
 
+    def phases(self):
+        self.synchronize()
+        return dict((b[0], a[1].elapsed_time(b[1])) for a, b in zip(self._marks[:-1], self._marks[1:]))
 
-def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=True):
+
+class DistComm(object):
+    """The collectives of a sample-sharded frame on torch.distributed (RCCL when the backend is nccl)."""
+
+    def __init__(self):
+        self.rank, self.world = _world()
+
+    def exchange(self, acc2d, plan):
+        return exchange_bands(acc2d, plan, self.rank, self.world)
+
+    def gather_rows(self, mine):
+        allb = torch.empty((self.world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        if dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(allb, mine)
+        else:
+            dist.all_gather(list(allb.view((self.world,) + tuple(mine.shape)).unbind(0)), mine)
+        return allb
+
+    def sum(self, acc):
+        return sum_accumulators(acc)
+
+
+def sharded_frame_steps(mgr, rdr, gnm, gprof, tc, rank, world, device=None, copy=True, bands=True):
     """
-    RenderManager.queue_frame for ONE frame split by samples over all ranks.  Every rank must
-    call it (it contains the collective) with a RenderManager built with
-    ``host_seed=rank_seed(seed)``; every rank ends up with the finished frame.
-    Returns ``(evt, h_out)`` like queue_frame (cuburn/render.py:374-434).
+    One sample-sharded frame as a generator: it yields at the frame's collectives — ``('exchange', acc2d, plan)``,
+    to be answered (``send``) with ``(band, top)``; ``('gather', mine)``, answered with the gathered rows of all ranks;
+    ``('sum', acc)``, answered with anything once the accumulator has been summed in place — and returns
+    ``(evt, h_out)`` (StopIteration.value).  queue_frame_sharded drives it with torch.distributed; a test can drive the
+    generators of several virtual ranks of one process.  Nothing in here waits on the host: the native context's
+    lane and torch's stream are ordered by events (order_streams), so that with two frames queued ahead the next
+    frame's iterate kernels run under this frame's exchange and filters.
     """
     from . import _lib
     from .render import DurationEvent
     lib = _lib.load()
-    rank, world = _world()
     if device is None:
         device = torch.cuda.current_device()
     fb = mgr.fb
-    dim = fb.set_dim(gprof.width, gprof.height, nsamples=sample_share(gprof.spp(tc) * gprof.width * gprof.height, rank, world))
+    total = gprof.spp(tc) * gprof.width * gprof.height
+    # the walker geometry follows the NOMINAL share, the same on every rank (a rank's own share differs by one sample)
+    dim = fb.set_dim(gprof.width, gprof.height, nsamples=int(total) // world)
     td = gprof.frame_width(tc) / round(gprof.fps * gprof.duration)
     ts = tc - 0.5 * td
     g = rdr._handle(fb)
@@ -437,8 +486,15 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=
     _lib.check(lib.fl_frame_begin(fb.ctx, C.byref(fid)))
     if copy:
         mgr._copy(rdr, gnm)
+    marks = []
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(device))
+        marks.append((name, e))
+    mark('start')
     _lib.check(lib.fl_interp(fb.ctx, g, dim.w, dim.h, ts, td))
-    nsamps = sample_share(gprof.spp(tc) * dim.w * dim.h, rank, world)
+    nsamps = sample_share(total, rank, world)
     run = C.c_uint64()
     _lib.check(lib.fl_iterate(fb.ctx, g, dim.w, dim.h, float(nsamps), mgr.fuse,
                               mgr.resolve_accum_mode(dim), C.byref(run)))
@@ -446,36 +502,62 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=
     plan = band_plan(dim.ah, world) if (bands and band_path_ok(rdr.out, dim, [f.name for f in rdr.filts])) else None
     if world > 1 and plan is not None:
         # row bands: reduce-scatter + halo exchange, filter and convert the band, all-gather the 8-bit rows
-        t_start = torch.cuda.Event(enable_timing=True)
-        t_start.record()
-        acc = accumulator_tensor(fb, device, dim).view(dim.ah, dim.astride * 4)      # waits for the iterate + flush kernels
-        band, top = exchange_bands(acc, plan, rank, world)
+        order_streams(fb, device, ctx_waits=False)                  # torch's stream behind the iterate + flush kernels
+        mark('iterate')
+        acc = accumulator_tensor(fb, device, dim, wait=False).view(dim.ah, dim.astride * 4)
+        band, top = yield ('exchange', acc, plan)
+        mark('exchange')
         rows_per, ranges = plan
         r0, r1 = ranges[rank]
-        g = fb.gutter
+        gut = fb.gutter
         mine = torch.zeros((rows_per, dim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=acc.device)
         out, bdim = filter_band(mgr, rdr, gprof, dim, band, tc, device)
         # image rows of this band: accumulator rows [r0, r1) less the frame's own gutter rows
-        y0, y1 = max(r0 - g, 0), min(r1 - g, dim.h)
+        y0, y1 = max(r0 - gut, 0), min(r1 - gut, dim.h)
         if y1 > y0:
-            j0 = y0 + g - (r0 - top) - g                 # band output row of image row y0
-            _lib.check(lib.fl_ctx_sync(fb.ctx))
-            mine[y0 + g - r0:y1 + g - r0] = out[j0:j0 + (y1 - y0)]
-        allb = torch.empty((world * rows_per, dim.w, 4), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(allb, mine) if dist.get_backend() == 'nccl' else dist.all_gather(list(allb.view(world, rows_per, dim.w, 4).unbind(0)), mine)
-        frame = allb[g:g + dim.h]
+            j0 = y0 + gut - (r0 - top) - gut             # band output row of image row y0
+            mine[y0 + gut - r0:y1 + gut - r0] = out[j0:j0 + (y1 - y0)]
+        mark('filter')
+        allb = yield ('gather', mine)
+        frame = allb[gut:gut + dim.h]
         # asynchronous copy into the pinned frame buffer; the handle completes when the copy has (render.py:26-38)
         h_out = fb.host_buffer(rdr.out.shape(dim), rdr.out.dtype)
         torch.from_numpy(h_out.view(np.uint8 if rdr.out.dtype == 'u1' else np.int16)).copy_(frame, non_blocking=True)
-        t_end = torch.cuda.Event(enable_timing=True)
-        t_end.record()
-        return TorchFrameEvent(t_start, t_end, keep=(allb, frame)), h_out
+        mark('gather')
+        evt = TorchFrameEvent(marks, keep=(allb, frame, out, mine, band))
+        fb._track(evt)
+        return evt, h_out
     if world > 1:
-        acc = accumulator_tensor(fb, device, dim)      # waits for the iterate + flush kernels
-        sum_accumulators(acc)
-        torch.cuda.synchronize(device)
+        order_streams(fb, device, ctx_waits=False)
+        acc = accumulator_tensor(fb, device, dim, wait=False)
+        yield ('sum', acc)
+        order_streams(fb, device, ctx_waits=True)                   # the filters behind the all-reduce
     for filt in rdr.filts:
         filt.apply(fb, gprof, getattr(gprof.filters, filt.name), dim, tc)
     rdr.out.convert(fb, gprof, dim)
     h_out = rdr.out.copy(fb, dim)
     return DurationEvent(fb, fid.value), h_out
+
+
+def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=True, comm=None):
+    """
+    RenderManager.queue_frame for ONE frame split by samples over all ranks.  Every rank must
+    call it (it contains the collectives) with a RenderManager built with
+    ``host_seed=rank_seed(seed)``; every rank ends up with the finished frame.
+    Returns ``(evt, h_out)`` like queue_frame (cuburn/render.py:374-434); ``h_out`` is valid once
+    ``evt.synchronize()`` has returned (or ``evt.query()`` is true): nothing in here waits on the host.
+    """
+    comm = comm or DistComm()
+    steps = sharded_frame_steps(mgr, rdr, gnm, gprof, tc, comm.rank, comm.world, device=device, copy=copy, bands=bands)
+    reply = None
+    try:
+        while True:
+            req = steps.send(reply)
+            if req[0] == 'exchange':
+                reply = comm.exchange(req[1], req[2])
+            elif req[0] == 'gather':
+                reply = comm.gather_rows(req[1])
+            else:
+                reply = comm.sum(req[1])
+    except StopIteration as done:
+        return done.value

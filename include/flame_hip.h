@@ -273,6 +273,16 @@ int fl_write_buffer(fl_ctx *ctx, fl_genome *g, int which, const void *host_src, 
  * stream), synchronises that stream, and continues with fl_filter / fl_output.  The reference has
  * no such step (distribute.py:149-163 shards whole frames only). */
 int fl_buffer_ptr(fl_ctx *ctx, fl_genome *g, int which, void **dev_ptr, size_t *nbytes);
+/* The same without blocking the host (round 5): the address is handed out at once, and what the caller queues on a stream of its
+ * own is ordered against the context's work with fl_stream_dependency.  The reference orders its two streams the same way —
+ * an event recorded on one, stream.wait_for_event on the other, no host wait inside a frame (cuburn/render.py:358-364,419-430;
+ * distribute.py:107-122 is its double-buffered loop). */
+int fl_buffer_ptr_async(fl_ctx *ctx, fl_genome *g, int which, void **dev_ptr, size_t *nbytes);
+/* Order the context's current lane and a caller's HIP stream (`stream`: a hipStream_t, e.g. torch's current stream, on which the
+ * caller runs a collective over buffers obtained above) without a host wait.  ctx_waits = 0: everything queued on the lane so far
+ * (deferred filter steps included) happens before whatever the caller queues on `stream` next; ctx_waits = 1: everything queued
+ * on `stream` so far happens before whatever the context queues on the lane next. */
+int fl_stream_dependency(fl_ctx *ctx, void *stream, int ctx_waits);
 
 /* Single-launch taps for bit-exact tests: run `nrounds` rounds (first `fuse` write-disabled)
  * for every slot with the given global round counter, no clears, no flush. */

@@ -1003,6 +1003,78 @@ def test_8k_wide_binned_equals_atomic(mgr):
 
 
 # ---------------------------------------------------------------------------------- sample sharding
+def test_sample_sharded_frame_never_waits_on_the_host(built):
+    """queue_frame_sharded's body (distributed.sharded_frame_steps) for TWO VIRTUAL RANKS of one process: two managers with
+    the ranks' seeds, the collectives stood in for by device operations on torch's stream (sum of the two accumulators cut
+    into the band + halos; concatenation of the ranks' rows).  The native lanes and torch's stream are ordered by events only
+    (fl_stream_dependency): when the second rank's call returns, the GPU still has most of the frame's work in front of it
+    — a host wait anywhere between fl_iterate and the return would have drained it (round 4 had four).  And the frame is the
+    frame: bands, halos and rows land where an unsharded render puts them."""
+    import time
+    import torch
+    from cuburn_amd import distributed as D
+    gnm, prof = configs.cfg2(samples=2 ** 31)                     # 2^30 samples per rank: ~10 ms of GPU work for the two of them
+    gprof = profile.wrap(prof, gnm)
+    tc = 0.5
+    world = 2
+    mgrs = [render.RenderManager(device=0, host_seed=D.rank_seed(42, r)) for r in range(world)]
+    rdrs = [render.Renderer(gnm, gprof) for _ in range(world)]
+
+    def frame():
+        gens = [D.sharded_frame_steps(mgrs[r], rdrs[r], gnm, gprof, tc, r, world, device=0) for r in range(world)]
+        reqs = [next(g) for g in gens]                            # both ranks: interp + iterate queued, at the exchange
+        assert all(q[0] == 'exchange' for q in reqs)
+        plan = reqs[0][2]
+        rows_per, bands = plan
+        total = reqs[0][1] + reqs[1][1]                           # stand-in for the reduce-scatter's sum
+        ah = total.shape[0]
+        replies = []
+        for r in range(world):
+            hp = D.halo_plan(plan, r, ah)
+            r0, r1 = bands[r]
+            replies.append((total[r0 - hp['top']:r1 + hp['bot']].clone(), hp['top']))
+        reqs = [g.send(rep) for g, rep in zip(gens, replies)]     # both ranks: band filtered + converted, at the gather
+        assert all(q[0] == 'gather' for q in reqs)
+        allb = torch.cat([q[1] for q in reqs])
+        done = []
+        for g in gens:
+            try:
+                g.send(allb)
+                raise AssertionError('the generator should have finished')
+            except StopIteration as fin:
+                done.append(fin.value)
+        return done
+
+    for _ in range(2):                                            # warm up: per-genome kernel, buffers, pinned memory
+        for evt, _h in frame():
+            evt.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = frame()
+    t_host = time.perf_counter() - t0
+    busy = [not evt.query() for evt, _h in done]
+    for evt, _h in done:
+        evt.synchronize()
+    t_all = time.perf_counter() - t0
+    assert all(busy), 'the frames had finished when queue_frame_sharded returned: something waited on the host'
+    assert t_host < 0.6 * t_all, (t_host, t_all)
+    ph = done[0][0].phases()
+    assert set(ph) == {'iterate', 'exchange', 'filter', 'gather'} and all(v >= 0 for v in ph.values())
+    # every virtual rank holds the same finished frame, and it is the unsharded frame up to sampling noise
+    a, b = np.array(done[0][1]), np.array(done[1][1])
+    assert np.array_equal(a, b) and a.shape == (1080, 1920, 4) and a[..., :3].max() > 50
+    whole = []
+    for _ in range(2):
+        evt, h = mgrs[1].queue_frame(rdrs[1], gnm, gprof, tc)
+        evt.synchronize()
+        whole.append(np.array(h)[..., :3].astype(np.float64))
+    floor = np.abs(whole[0] - whole[1]).mean()
+    diff = max(np.abs(a[..., :3] - whole[0]).mean(), np.abs(a[..., :3] - whole[1]).mean())
+    assert diff < 1.25 * floor + 0.25, (diff, floor)
+    for m in mgrs:
+        m.fb.free()
+
+
 def test_sample_sharded_frame_two_virtual_ranks(built):
     """a frame split by samples.  Two contexts with the per-rank seeds each iterate
     their share; the accumulators are summed through the zero-copy torch views that the RCCL
