@@ -606,7 +606,7 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         hipFunction_t &slot = g->rtc_fn[c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
         if (!slot) {
             std::string err;
-            if (rtc_iter_kernel(c->device, g->spec, c->nw, count, kacc, &slot, &err)) {
+            if (rtc_iter_kernel(c->device, g->spec, c->nw, c->nslots, count, kacc, &slot, &err)) {
                 g->rtc_failed = true;
                 slot = nullptr;
                 fprintf(stderr, "libflame_hip: per-genome kernel not available (%s); using the interpreter kernel\n", err.c_str());

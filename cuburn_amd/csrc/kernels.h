@@ -43,7 +43,7 @@ struct IterSpec {
 bool rtc_available();
 unsigned rtc_epoch();      // changes when cached modules were unloaded: function handles obtained before are void
 int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt = nullptr);
-int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err);
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err);
 // launch_iter through a run-time compiled kernel (same arguments)
 void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t nslots,
                     const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,

@@ -175,16 +175,21 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 
 unsigned rtc_epoch() { std::lock_guard<std::mutex> lock(g_mu); return g_epoch; }
 
-int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int acc, hipFunction_t *fn, std::string *err)
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err)
 {
-    const std::string key = std::to_string(device) + "|" + spec_header(spec, nw, count, acc);
+    // vector registers a four-wave kernel may use before a workgroup per CU is lost: every slot is resident at once, nslots * 4
+    // waves over 1024 SIMDs of 512 registers each — 128 at the 1024 slots of frames of up to 2^28 samples (four waves per SIMD),
+    // 80 at 1536 (six; the allocation granule is 8).  Other geometries are bounded by LDS, not registers: no limit.
+    const uint32_t wps = (nslots * 4u + 1023u) / 1024u;
+    const int reg_limit = nw == 4 && wps >= 1u && wps <= 8u ? (int)(512u / wps / 8u * 8u) : 0;
+    const std::string key = std::to_string(device) + "|" + std::to_string(reg_limit) + "|" + spec_header(spec, nw, count, acc);
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn = it->second.fn; return 0; }
-    // Four-wave workgroups run six to a CU in the 1536-slot geometry (six waves per SIMD: 80 vector registers).  The kernel keeps
-    // wave-uniform operands of the round in vector registers (FL_HOIST_BUDGET, iter.hip); where that is what takes a genome's
-    // kernel past 80, it is compiled again with a smaller budget — a sixth of the workgroups waiting for a slot costs far more
-    // than the few instructions per round the registers save.
+    // The kernel keeps wave-uniform operands of the round in vector registers (FL_HOIST_BUDGET, iter.hip); where that is what takes a
+    // genome's kernel past the geometry's register limit, it is compiled again with a smaller budget — a sixth of the workgroups
+    // waiting for a slot costs far more than the few instructions per round the registers save.  (Round 4 compared with 80 whatever
+    // the geometry: kernels of 81-128 registers were recompiled up to three times for the 1024-slot geometry, for nothing.)
     Entry e;
     const char *budgets[] = {nullptr, "-DFL_HOIST_BUDGET=7", "-DFL_HOIST_BUDGET=5", "-DFL_HOIST_BUDGET=0"};
     Entry first; bool have_first = false;
@@ -198,10 +203,11 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, bool count, int ac
         }
         int regs = 0;
         if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, t.fn) != hipSuccess) { (void)hipGetLastError(); regs = 0; }
-        if (nw != 4 || regs <= 80) { if (have_first) (void)hipModuleUnload(first.mod); have_first = false; e = t; break; }
+        if (reg_limit == 0 || regs <= reg_limit) { if (have_first) (void)hipModuleUnload(first.mod); have_first = false; e = t; break; }
         if (!have_first) { first = t; have_first = true; } else (void)hipModuleUnload(t.mod);
     }
-    if (have_first) e = first;          // over 80 with every budget: the registers are not the hoisted operands — keep the full budget
+    if (have_first) e = first;          // over the limit with every budget: the registers are not the hoisted operands — keep the full budget
+    err->clear();                       // (a later budget's failure text must not outlive a successful result)
     if (g_cache.size() >= kMaxModules) {
         // simple bound: drop THIS device's modules (the current device is `device`: its queued kernels are
         // waited for first); modules of other devices held by the process stay loaded — their kernels may

@@ -18,7 +18,15 @@
 // CUDA's library function under -use_fast_math, 2-3 ulp).  min / max -> one hardware reciprocal -> atan(q) = q + q^3 P(q^2) on [0, 1]
 // (own least-squares minimax fit, degree 6 in q^2: 1.2e-7 absolute, 2.9e-7 relative in float arithmetic) -> octant fix-ups.
 // atan2(0, 0) = 0; NaN in, NaN out; both operands infinite gives NaN (such a point is discarded by the caller either way).
-#ifndef FL_LIBM_ATAN2
+// Ranges the lean forms do NOT cover (the CPU oracle takes libm's answer there; such points lie outside any picture, and a walker
+// that reaches them is re-seeded within a few rounds): v_atan2 with max(|a|, |b|) > 2^126 — the reciprocal is a denormal, flushed: the
+// angle comes out as 0 or pi/2 — or with BOTH operands denormal (the FLT_MIN clamp); v_fmod with |b| > 2^126 (one subtraction
+// where up to three may be needed); v_fmod_pi next to multiples of pi, where the result may be a few ulp of pi below 0 or at pi.
+// -DFL_LIBM_MATH (through FLAME_RTC_FLAGS; FL_LIBM_ATAN2 is its round-4 name) compiles the device library's functions back in.
+#if defined(FL_LIBM_ATAN2) && !defined(FL_LIBM_MATH)
+#define FL_LIBM_MATH 1
+#endif
+#ifndef FL_LIBM_MATH
 __device__ __forceinline__ float v_atan2(float a, float b)
 {
     const float ax = fabsf(b), ay = fabsf(a);
@@ -43,7 +51,7 @@ __device__ __forceinline__ float v_atan2(float a, float b) { return atan2f(a, b)
 // CUDA's library functions over ex2.approx under -use_fast_math).  h = e^|x| / 2 from ONE v_exp_f32 (the halving in the exponent, so that
 // nothing overflows before the result does), cosh = h + 1/(4h), sinh = h - 1/(4h); below |x| = 0.5, where that difference cancels, the
 // odd series to x^9 / 9! (next term 1.2e-11 relative).  The thirteen trigonometric / hyperbolic variations (sin .. coth) call both.
-#ifndef FL_LIBM_ATAN2
+#ifndef FL_LIBM_MATH
 __device__ __forceinline__ float v_cosh(float x)
 {
     const float h = fexp2(fmaf(fabsf(x), FM_LOG2E, -1.0f));
@@ -66,7 +74,7 @@ __device__ __forceinline__ float v_sinh(float x) { return sinhf(x); }
 // r = a - q b in one fma, then the two ways q can be off by one put right (|r| >= |b|: q too small; r on the wrong side of 0: q too
 // big) — the result has the sign of a, magnitude below |b|, and differs from the exact remainder by the fma's rounding only.
 // Larger quotients (and b = 0, NaN) take the device library's exact loop, 45 instructions + 1-2 rounds, which every call paid before.
-#ifndef FL_LIBM_ATAN2
+#ifndef FL_LIBM_MATH
 __device__ __forceinline__ float v_fmod(float a, float b)
 {
     const float qf = a * frcp(b);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 4: what the lean sinh / cosh of variations.h buy a flame that uses the trigonometric / hyperbolic variations (cfg2 with its three
 variations replaced by cosh, sech and csc): frame time through queue_frame, lean forms against the device library's
-(FLAME_RTC_FLAGS=-DFL_LIBM_ATAN2 compiles the per-genome kernel with the latter).   python tools/exp_hyp.py"""
+(FLAME_RTC_FLAGS=-DFL_LIBM_MATH compiles the per-genome kernel with the latter).   python tools/exp_hyp.py"""
 import os, subprocess, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
@@ -26,5 +26,5 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
         dt = time.perf_counter() - t0
     print('%-18s %.3f ms per frame' % (os.environ.get('FLAME_RTC_FLAGS', '') or 'lean', dt / n * 1e3))
 else:
-    for flags in ('', '-DFL_LIBM_ATAN2', '', '-DFL_LIBM_ATAN2'):
+    for flags in ('', '-DFL_LIBM_MATH', '', '-DFL_LIBM_MATH'):
         subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, FLAME_RTC_FLAGS=flags), stderr=subprocess.DEVNULL)
