@@ -18,7 +18,7 @@
 // CUDA's library function under -use_fast_math, 2-3 ulp).  min / max -> one hardware reciprocal -> atan(q) = q + q^3 P(q^2) on [0, 1]
 // (own least-squares minimax fit, degree 6 in q^2: 1.2e-7 absolute, 2.9e-7 relative in float arithmetic) -> octant fix-ups.
 // atan2(0, 0) = 0; NaN in, NaN out; both operands infinite gives NaN (such a point is discarded by the caller either way).
-// Ranges the lean forms do NOT cover (the tests. CPU restatement takes libm's answer there; such points lie outside any picture, and a walker
+// Ranges the lean forms do NOT cover (the tests' CPU restatement takes libm's answer there; such points lie outside any picture, and a walker
 // that reaches them is re-seeded within a few rounds): v_atan2 with max(|a|, |b|) > 2^126 — the reciprocal is a denormal, flushed: the
 // angle comes out as 0 or pi/2 — or with BOTH operands denormal (the FLT_MIN clamp); v_fmod with |b| > 2^126 (one subtraction
 // where up to three may be needed); v_fmod_pi next to multiples of pi, where the result may be a few ulp of pi below 0 or at pi.
