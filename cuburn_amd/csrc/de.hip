@@ -126,6 +126,9 @@ __host__ __device__ constexpr bool de_hoisted(int P) { return P < 4; }      // i
 #ifndef DE_SKIP_OUTSIDE
 #define DE_SKIP_OUTSIDE 1
 #endif
+#ifndef DE_BOTTOM_FIRST
+#define DE_BOTTOM_FIRST 1
+#endif
 #ifndef DE_RUN
 #define DE_RUN 8u             /* tile order 2: tiles per run (a run stays on one XCD) */
 #endif
@@ -572,6 +575,9 @@ k_de_dir(fl_dim d, float4 *__restrict__ Nout_, const float4 *__restrict__ N_, De
         if (rm >= ntiles) return;
         const uint32_t q = tiles_x == 1u ? rm : __umulhi(rm, magic);    // rm / tiles_x
         ty = (int)q; tx = (int)(rm - q * tiles_x);
+        // (the bottom row of tiles first: its tiles touch the image's edge — the slow ones, frame tables — and dispatched last they
+        // WERE the kernel's tail; the top row, the other slow one, has always been first)
+        if (DE_BOTTOM_FIRST) ty = ty == 0 ? (int)tiles_y - 1 : ty - 1;
     }
     // x of column 0 of tile row 0; for K > 0 the band starts SPAN to the left so that its last row reaches x = 0
     const int bx0 = tx * G::TW - (G::K > 0 ? G::SPAN : 0), by0 = ty * G::TH;
