@@ -72,8 +72,9 @@ struct Lane {
 struct fl_ctx {
     int device = 0;
     bool own_stream = false;
-    int nlanes = 2, cur = 0;
-    Lane lanes[2];
+    static const int kMaxLanes = 4;
+    int nlanes = 2, cur = 0;          // FLAME_LANES (1..4; default 2): consecutive frames go round the lanes
+    Lane lanes[kMaxLanes];
     uint32_t nslots = 0, nwalkers = 0;
     int nw = 4;                       // waves per iterate workgroup
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
@@ -83,7 +84,7 @@ struct fl_ctx {
     uint32_t bin_rounds = 16, bin_parts = 0;      // bin_parts 0: chosen per image (see do_iter_launch)
     uint32_t launch_rounds = 0;                   // FLAME_LAUNCH_ROUNDS: write-enabled rounds per binned launch (0: FL_BIN_MAX_ROUNDS) — the sample log of a launch is nslots x 256 x rounds x 4 bytes
     uint32_t round_counter = 0;
-    static const uint32_t kFrames = 4;            // frames that may be in flight (reference: 2)
+    static const uint32_t kFrames = 8;            // frames that may be in flight (reference: 2)
     hipEvent_t ev_begin_[kFrames] = {}, ev_end_[kFrames] = {};
     uint32_t frame_lane[kFrames] = {};
     uint32_t frame_seq = 0;                        // id of the current frame = frame_seq - 1
@@ -99,7 +100,7 @@ struct fl_ctx {
     uint32_t n_spec_launch = 0, n_interp_launch = 0;      // iterate launches by kernel since fl_timings_reset (fl_launch_stats)
 };
 #define L(c) ((c)->lanes[(c)->cur])
-#define OTHER(c) ((c)->lanes[(c)->cur ^ 1])
+#define OTHER(c) ((c)->lanes[((c)->cur + (c)->nlanes - 1) % (c)->nlanes])      /* the previous frame's lane: it touched the shared state last */
 #define FL_NOUT 65536u                // RNG states reserved for the output dither kernel
 
 struct fl_genome {
@@ -242,7 +243,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->nw = nw;
     c->nslots = nslots;
     c->nwalkers = nslots * (uint32_t)nw * 64 + FL_PAL_H * 256 + FL_NOUT;
-    if (const char *e = getenv("FLAME_LANES")) c->nlanes = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("FLAME_LANES")) { const int v = atoi(e); c->nlanes = v >= 1 && v <= fl_ctx::kMaxLanes ? v : 2; }
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
     if (const char *e = getenv("FLAME_BIN_PARTS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->bin_parts = (uint32_t)v; }
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
@@ -302,11 +303,11 @@ void fl_ctx_destroy(fl_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     for (uint32_t i = 0; i < fl_ctx::kDepEvents; ++i) if (c->dep_ev[i]) hipEventDestroy(c->dep_ev[i]);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < fl_ctx::kMaxLanes; ++i) {
         if (c->lanes[i].stream) hipStreamSynchronize(c->lanes[i].stream);
         if (c->lanes[i].aux) hipStreamSynchronize(c->lanes[i].aux);
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < fl_ctx::kMaxLanes; ++i) {
         c->cur = i;
         free_fb(c);
         Lane &ln = c->lanes[i];
@@ -502,7 +503,7 @@ int fl_frame_begin(fl_ctx *c, uint32_t *frame_id)
     HIPCHK(hipSetDevice(c->device));
     const uint32_t id = c->frame_seq++;
     const uint32_t k = id % fl_ctx::kFrames;
-    c->cur = c->nlanes == 2 ? (int)(id & 1u) : 0;          // consecutive frames alternate lanes
+    c->cur = (int)(id % (uint32_t)c->nlanes);             // consecutive frames go round the lanes
     c->frame_lane[k] = (uint32_t)c->cur;
     HIPCHK(hipEventRecord(c->ev_begin_[k], L(c).stream));
     HIPCHK(hipEventRecord(c->ev_end_[k], L(c).stream));       // moved forward by fl_output

@@ -148,10 +148,10 @@ class Framebuffers(object):
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def host_buffer(self, shape, dtype):
-        """Page-locked output buffers, rotated so that up to three frames may be in flight."""
+        """Page-locked output buffers, rotated so that up to five frames may be in flight."""
         key = (tuple(shape), dtype)
         if key not in self._host:
-            self._host[key] = [self._pinned(shape, dtype) for _ in range(3)]
+            self._host[key] = [self._pinned(shape, dtype) for _ in range(5)]
         ring = self._host[key]
         ring.append(ring.pop(0))
         return ring[-1]

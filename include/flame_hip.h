@@ -306,7 +306,8 @@ int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
 
 /* ---- run-time switches (environment; read when a context is created / a kernel is first launched) ----
  * Every switch is an A/B lever of a documented measurement, none changes results beyond float summation order:
- *   FLAME_LANES=1            one stream lane instead of two (kernel timing; profiles/ are taken with it)
+ *   FLAME_LANES=n            stream lanes, 1..4 (default 2: consecutive frames alternate; 1 for kernel timing — profiles/ are taken with it;
+ *                            3 and 4 measure the same as 2, profiles/r05_lanes.txt)
  *   FLAME_NO_INTRA_OVERLAP=1 the launches of a multi-launch frame strictly in series on one stream
  *   FLAME_RTC=0              always the precompiled interpreter iterate kernel (no hipRTC per-genome kernel)
  *   FLAME_RTC_FLAGS=...      extra options for the hipRTC compile; FLAME_RTC_DUMP=<dir> keeps its source / assembly
