@@ -53,3 +53,13 @@ for d, se, t, w in ses:
     st = rows[(d, 'stage')][5] if (d, 'stage') in rows else float('nan')
     model = rate * se * w / 1024e3
     print('%-4d %10.1f %10.1f %10.1f %10.1f %10.1f %+7.1f%%' % (d, st, se - st, se, model, t, 100 * (model - t) / t))
+# the same with a fixed cost per launch (ramp-up and tail: every workgroup stages at once at the start, few are left at the end)
+xs = [se * w / 1024e3 for d, se, t, w in ses]; ts = [t for d, se, t, w in ses]
+n = float(len(xs)); sx, sy = sum(xs), sum(ts); sxx = sum(x * x for x in xs); sxy = sum(x * y for x, y in zip(xs, ts))
+a2 = (n * sxy - sx * sy) / (n * sxx - sx * sx); c2 = (sy - a2 * sx) / n
+print()
+print('with a fixed cost per launch: %.3f ns per slot-equivalent per SIMD + %.1f us per launch' % (a2, c2))
+print('%-4s %10s %10s %8s' % ('dir', 'model us', 'measured', 'error'))
+for (d, se, t, w), x in zip(ses, xs):
+    m = a2 * x + c2
+    print('%-4d %10.1f %10.1f %+7.1f%%' % (d, m, t, 100 * (m - t) / t))
