@@ -352,6 +352,21 @@ BAND_WORKER = textwrap.dedent('''
         assert np.allclose(band.numpy(), want, rtol=1e-6, atol=0), ah
         done += 1
     assert done >= (2 if world <= 4 else 1), done
+    # the collectives object queue_frame_sharded drives its generator with (round 5): same exchange, rows gathered in rank order
+    comm = D.DistComm()
+    assert (comm.rank, comm.world) == (rank, world)
+    plan = D.band_plan(1104, world) or D.band_plan(4352, world)
+    ahc = plan[1][-1][1]
+    acc = torch.from_numpy(np.random.RandomState(7 + rank).rand(ahc, 12).astype(np.float32))
+    b1, t1 = comm.exchange(acc.clone(), plan)
+    b2, t2 = D.exchange_bands(acc.clone(), plan, rank, world)
+    assert t1 == t2 and torch.equal(b1, b2)
+    mine = torch.full((plan[0], 5, 4), rank + 1, dtype=torch.uint8)
+    allb = comm.gather_rows(mine)
+    assert allb.shape == (world * plan[0], 5, 4)
+    assert [int(allb[r * plan[0], 0, 0]) for r in range(world)] == list(range(1, world + 1))
+    s = comm.sum(torch.ones(4) * (rank + 1))
+    assert float(s[0]) == world * (world + 1) / 2
     if rank == 0:
         print('BANDS_OK')
     dist.barrier()
