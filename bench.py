@@ -385,7 +385,10 @@ def main():
                 for k in pmc:
                     if sub in k:
                         c = pmc[k]
-                        tot += (2 * c['FETCH_SIZE']['median_per_launch'] + c['WRITE_SIZE']['median_per_launch']) * 1024
+                        # (launches of one frame differ in length when it has more than 1024 rounds: launches x MEAN is the frame's sum;
+                        # files of rounds 1-5a carry the median only)
+                        per = 'mean_per_launch' if 'mean_per_launch' in c['FETCH_SIZE'] else 'median_per_launch'
+                        tot += (2 * c['FETCH_SIZE'][per] + c['WRITE_SIZE'][per]) * 1024
                 return tot
             if args.accum == 'binned':
                 # per LAUNCH in the file; a frame of more than 2^28 samples has several iterate / accumulate / flush launches

@@ -249,7 +249,7 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     c->env_bin_wide = env_on("FLAME_BIN_WIDE");
     if (const char *e = getenv("FLAME_RTC")) c->use_rtc = strcmp(e, "0") != 0;
     c->env_no_intra = env_on("FLAME_NO_INTRA_OVERLAP");      // launches of a frame strictly in series on one stream
-    if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 1024) c->launch_rounds = (uint32_t)(v / 16 * 16); }
+    if (const char *e = getenv("FLAME_LAUNCH_ROUNDS")) { int v = atoi(e); if (v >= 16 && v <= 4096) c->launch_rounds = (uint32_t)(v / 16 * 16); }
     if (stream) { c->lanes[0].stream = (hipStream_t)stream; c->own_stream = false; c->nlanes = 1; }   // caller's stream: one lane
     else c->own_stream = true;
     // every failure below leaves through fl_ctx_destroy, which frees whatever exists so far
@@ -549,8 +549,13 @@ static int do_clear(fl_ctx *c, const fl_dim &d, bool reset_points)
     return FL_OK;
 }
 
-// Maximum write-enabled rounds of one binned launch (bounds the sample log: nslots*NT*4 B per round)
+// Maximum write-enabled rounds of one binned launch (bounds the sample log: nslots*NT*4 B per round).  The reference's batches grow
+// 1024, 1536, 2304, ... rounds (cuburn/render.py:338-369); here they stop growing at 1024 — equal launches overlap best in the
+// lane's two-stream pipeline (cfg3, 2731 rounds: 1024 + 1024 + 683 is 1.7 % faster than 1024 + 1536 + 171) — unless following the
+// reference's schedule up to 2304 rounds saves a launch, i.e. a flush and a zeroed + added tile per workgroup (cfg5, 4096 rounds:
+// 1024 + 1536 + 1536 instead of 4 x 1024, frame 37.0 -> 36.1 ms; profiles/r05_launch_cap.txt).
 #define FL_BIN_MAX_ROUNDS 1024u
+#define FL_BIN_MAX_ROUNDS_LONG 2304u
 
 static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, int buf, uint32_t *tiles_x, uint32_t *nbins,
                          uint32_t *nbatch_total, bool *wide)
@@ -685,9 +690,10 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     // + flush of each launch go to the lane's aux stream, with two log / directory sets: launch k+1
     // iterates while launch k drains.  (Both kernels want the whole chip, so this buys little —
     // DESIGN.md §4.1 — but it costs nothing and hides the drains' launch gaps.)
-    const uint64_t cap = accum_mode == FL_ACCUM_BINNED ? (c->launch_rounds ? c->launch_rounds : FL_BIN_MAX_ROUNDS) : ~0ull;
-    uint32_t nlaunch = 0;
-    for (uint64_t r = rounds, b = 4; r; b += b / 2) { uint64_t n = std::min(std::min(r, b * 256), cap); r -= n; ++nlaunch; }
+    auto launches_with = [rounds](uint64_t cap_) { uint32_t nl = 0; for (uint64_t r = rounds, b = 4; r; b += b / 2) { r -= std::min(std::min(r, b * 256), cap_); ++nl; } return nl; };
+    const uint64_t cap = accum_mode != FL_ACCUM_BINNED ? ~0ull : c->launch_rounds ? c->launch_rounds :
+                         launches_with(FL_BIN_MAX_ROUNDS_LONG) < launches_with(FL_BIN_MAX_ROUNDS) ? FL_BIN_MAX_ROUNDS_LONG : FL_BIN_MAX_ROUNDS;
+    const uint32_t nlaunch = launches_with(cap);
     const bool pipelined = accum_mode == FL_ACCUM_BINNED && nlaunch > 1 && !c->env_no_intra;
     hipStream_t drain = pipelined ? L(c).aux : L(c).stream;
     uint64_t batch = 4;

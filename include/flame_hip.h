@@ -315,7 +315,8 @@ int fl_debug_counters(fl_ctx *ctx, uint64_t out4[4]);
  *   FLAME_BIN_PARTS=n        workgroups per tile of the tile accumulate (default: by image size)
  *   FLAME_BIN_GANG=n         adjacent tiles per XCD gang of the tile accumulate (default 32 above 512 tiles, else 0 = off)
  *   FLAME_BIN_WIDE=1         256x64 accumulate tiles for every image size
- *   FLAME_LAUNCH_ROUNDS=n    write-enabled rounds per iterate launch (default 1024)
+ *   FLAME_LAUNCH_ROUNDS=n    most write-enabled rounds per binned iterate launch, 16..4096 (default: the reference's growing batches
+ *                            capped at 1024 rounds, or at 2304 when that saves the frame a launch)
  *   FLAME_DE_ORDER=d|dddddddd tile order of the DE kernels, one digit for all or one per direction (0 per-XCD column-major runs,
  *                            1 row-major, 2 row-major in runs per XCD; default: by direction and image size, de.hip)
  * Compile-time timing builds (-DDE_X_*, -DACC_X_*) produce wrong pictures and exist only in libraries built for tools/. */

@@ -16,7 +16,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         per[r["Kernel_Name"].split("(")[0]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, d in per.items():
         vals = sorted(d.values())
-        out.setdefault(k, {})[ctr] = {"n": len(vals), "median_per_launch": vals[len(vals) // 2], "max": vals[-1]}
+        out.setdefault(k, {})[ctr] = {"n": len(vals), "median_per_launch": vals[len(vals) // 2], "max": vals[-1],
+                                      "mean_per_launch": sum(vals) / len(vals)}       # (a frame's launches differ in length: launches x mean = the frame)
 json.dump(out, open("gpurun_out/pmc_${tag}_traffic.json", "w"), indent=1, sort_keys=True)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("WRITE_SIZE", {}).get("median_per_launch", 0)):
     print(k[:60].ljust(60), {c: round(x["median_per_launch"], 1) for c, x in v.items()})
