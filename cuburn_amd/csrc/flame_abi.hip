@@ -76,6 +76,8 @@ struct fl_ctx {
     int nlanes = 2, cur = 0;          // FLAME_LANES (1..4; default 2): consecutive frames go round the lanes
     Lane lanes[kMaxLanes];
     uint32_t nslots = 0, nwalkers = 0;
+    bool pair = false;                            // 512 slots of 8 waves: two temporal samples per workgroup (iter.hip "Paired halves")
+    uint32_t ntemporal() const { return pair ? nslots * 2u : nslots; }      // temporal samples = parameter blocks per frame (>= FL_NTEMPORAL)
     int nw = 4;                       // waves per iterate workgroup
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
     float4 *d_points = nullptr;       // [nslots*NT]
@@ -107,7 +109,7 @@ struct fl_genome {
     uint64_t serial = 0;                    // unique per created genome (a lane remembers whose parameters its blocks hold)
     std::vector<int32_t> prog;
     IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
-    hipFunction_t rtc_fn[3][2][4] = {};     // [nw 4 / 8 / 16][count][acc] once compiled
+    hipFunction_t rtc_fn[4][2][4] = {};     // [nw 4 / 8 / 16 / 8 paired][count][acc] once compiled
     unsigned rtc_epoch = 0;                 // module-cache epoch the handles above belong to
     bool rtc_failed = false;                // compile / load failed once: stay on the interpreter kernel
     uint32_t nops = 0, nrows = 0, pstride = 0;
@@ -219,7 +221,8 @@ static bool env_on(const char *name) { const char *e = getenv(name); return e &&
 int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out)
 {
     REQUIRE(out && seeds, "null argument");
-    REQUIRE(nslots >= FL_NTEMPORAL && nslots % 256 == 0 && nslots <= 16384, "nslots must be a multiple of 256 in [1024, 16384]");
+    REQUIRE((nslots >= FL_NTEMPORAL || nslots == FL_NTEMPORAL / 2) && nslots % 256 == 0 && nslots <= 16384,
+            "nslots must be a multiple of 256 in [1024, 16384] (or 512 slots of 8 waves: two temporal samples per workgroup)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FL_E_NODEV, "no HIP device", __FILE__, __LINE__);
     REQUIRE(device >= 0 && device < ndev, "bad device index");
@@ -241,7 +244,10 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     fl_ctx *c = new fl_ctx;
     c->device = device;
     c->nw = nw;
+    if (nslots < FL_NTEMPORAL && nw != 8)
+        return fail(FL_E_INVAL, "512 slots need 8-wave workgroups (two temporal samples each: 1024 in all)", __FILE__, __LINE__);
     c->nslots = nslots;
+    c->pair = nslots < FL_NTEMPORAL;
     c->nwalkers = nslots * (uint32_t)nw * 64 + FL_PAL_H * 256 + FL_NOUT;
     if (const char *e = getenv("FLAME_LANES")) { const int v = atoi(e); c->nlanes = v >= 1 && v <= fl_ctx::kMaxLanes ? v : 2; }
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
@@ -520,7 +526,7 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     // at ts + s*td/nslots, so that every temporal sample receives the same number of iterations
     // whatever the slot count (the reference: one block column per each of its 1024 temporal
     // samples, cuburn/render.py:303-307,343-346; cuburn/code/iter.py:165,184).
-    const size_t need = (size_t)c->nslots * g->pstride;
+    const size_t need = (size_t)c->ntemporal() * g->pstride;     // (paired 8-wave workgroups: two blocks per slot)
     if (need > L(c).params_floats) {
         HIPCHK(hipStreamSynchronize(L(c).stream));
         hipFree(L(c).d_params); L(c).d_params = nullptr; L(c).params_floats = 0;
@@ -531,7 +537,7 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     { int rc = wait_other(c, 0); if (rc) return rc; }     // palette RNG states are shared
     launch_interp_palette(L(c).stream, rng_pal, g->d_ptimes, g->d_pals, ts, td / FL_PAL_H, L(c).d_palette);
     launch_interp_params(L(c).stream, L(c).d_params, g->d_times, g->d_knots, g->d_ops, g->nops, g->pstride,
-                         c->nslots, ts, td / (float)c->nslots, d, L(c).params_serial != g->serial);
+                         c->ntemporal(), ts, td / (float)c->ntemporal(), d, L(c).params_serial != g->serial);
     L(c).params_serial = g->serial;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L(c).ev_interp_done, L(c).stream));
@@ -609,10 +615,10 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     if (c->use_rtc && !g->rtc_failed && kacc != 2) {
         const unsigned ep = rtc_epoch();
         if (g->rtc_epoch != ep) { memset(g->rtc_fn, 0, sizeof g->rtc_fn); g->rtc_epoch = ep; }     // the module cache was flushed
-        hipFunction_t &slot = g->rtc_fn[c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
+        hipFunction_t &slot = g->rtc_fn[c->pair ? 3 : c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
         if (!slot) {
             std::string err;
-            if (rtc_iter_kernel(c->device, g->spec, c->nw, c->nslots, count, kacc, &slot, &err)) {
+            if (rtc_iter_kernel(c->device, g->spec, c->nw, c->nslots, count, kacc, &slot, &err, c->pair)) {
                 g->rtc_failed = true;
                 slot = nullptr;
                 fprintf(stderr, "libflame_hip: per-genome kernel not available (%s); using the interpreter kernel\n", err.c_str());
@@ -625,12 +631,12 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         launch_iter_fn(L(c).stream, fn, c->nw, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                        L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                        tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
-                       e ? e->a : nullptr, e ? e->b : nullptr);
+                       e ? e->a : nullptr, e ? e->b : nullptr, c->pair);
     else
     launch_iter(L(c).stream, c->nw, count, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                 tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
-                e ? e->a : nullptr, e ? e->b : nullptr);
+                e ? e->a : nullptr, e ? e->b : nullptr, c->pair);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
@@ -670,7 +676,7 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
 {
     REQUIRE(c && g, "null argument");
     REQUIRE(accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED || accum_mode == 2, "bad accumulation mode");
-    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
+    REQUIRE(L(c).params_floats >= (size_t)c->ntemporal() * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -1085,7 +1091,7 @@ int fl_debug_iter_launch(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, uint32
                          uint32_t nrounds, uint32_t fuse, int accum_mode)
 {
     REQUIRE(c && g && (accum_mode == FL_ACCUM_ATOMIC || accum_mode == FL_ACCUM_BINNED), "bad argument");
-    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
+    REQUIRE(L(c).params_floats >= (size_t)c->ntemporal() * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
     fl_dim d; fl_calc_dim(w, h, &d);
     int rc = ensure_fb(c, d);
@@ -1134,9 +1140,9 @@ int fl_debug_shuffle(fl_ctx *c, uint32_t round, uint32_t *out256)
 
 int fl_debug_apply_xf(fl_ctx *c, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng)
 {
-    REQUIRE(c && g && xyzw && rng && n > 0 && ts < c->nslots, "bad argument");
+    REQUIRE(c && g && xyzw && rng && n > 0 && ts < c->ntemporal(), "bad argument");
     REQUIRE(xfi >= 0 && xfi < g->prog[1] + g->prog[2], "xform index out of range");
-    REQUIRE(L(c).params_floats >= (size_t)c->nslots * g->pstride, "fl_interp has not run for this genome");
+    REQUIRE(L(c).params_floats >= (size_t)c->ntemporal() * g->pstride, "fl_interp has not run for this genome");
     HIPCHK(hipSetDevice(c->device));
     DevBuf dp, dr;
     HIPCHK(dp.alloc(16 * (size_t)n));

@@ -99,6 +99,10 @@ class Framebuffers(object):
     # stream lane's kernels run beside it.  With more samples the second launch costs more than the fuse saves
     # (profiles/r03_slots_by_samples.txt).  Decided per frame from its sample count (set_dim).
     NARROW_FEW = (4, 1024)
+    # The same for the 8-wave geometry (round 5): 512 slots whose two halves of four waves walk two temporal samples — the
+    # reference's 1024 samples x 256 threads exactly, bit for bit the walkers of NARROW_FEW, sharing 8192-record sort batches
+    # (csrc/iter.hip "Paired halves").  1024 slots of 8 waves walk 512 threads per sample: twice the un-plotted rounds.
+    WIDE_FEW = (8, 512)
     FEW_SAMPLES = 2 ** 28
     WIDE_FROM_TILES = 1024
     HUGE_FROM_TILES = 2047      # above 4K (where the accumulate switches to 256x64 tiles): 16-wave workgroups,
@@ -120,6 +124,7 @@ class Framebuffers(object):
     nw = property(lambda self: self._cfg[0])             # waves per iterate workgroup
     nslots = property(lambda self: self._cfg[1])
     nthreads = property(lambda self: self._cfg[0] * 64)
+    ntemporal = property(lambda self: self.nslots * 2 if self._cfg == self.WIDE_FEW else self.nslots)     # temporal samples per frame
     nwalkers = property(lambda self: self.nslots * self.nthreads + 64 * 256 + self.nout)
 
     @property
@@ -169,6 +174,11 @@ class Framebuffers(object):
                 if nsamples is not None:
                     want = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
                 elif self._cfg in (self.NARROW, self.NARROW_FEW):
+                    want = self._cfg
+            elif want == self.WIDE:
+                if nsamples is not None:
+                    want = self.WIDE_FEW if nsamples <= self.FEW_SAMPLES else self.WIDE
+                elif self._cfg in (self.WIDE, self.WIDE_FEW):
                     want = self._cfg
             if want != self._cfg:
                 self._drop_ctx()

@@ -60,8 +60,8 @@ typedef struct fl_mwc {
  *     values; normalisation per cuburn/genome/use.py:129-158.
  */
 #define FL_KNOTS 32
-#define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples = the minimum slot count here: there is one
-                               temporal sample per walker slot (fl_ctx_create nslots >= 1024), see fl_interp */
+#define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples = the minimum number of temporal samples here: one per
+                               walker slot (fl_ctx_create nslots >= 1024), or two per slot of 512 8-wave slots, see fl_interp */
 #define FL_PAL_W 256        /* cuburn/render.py:201-202 palette surface 256 x 64 */
 #define FL_PAL_H 64
 #define FL_GUTTER 12        /* cuburn/render.py:77 */
@@ -142,7 +142,9 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
  * `seeds` = nseeds x {mul,state,carry} as built by make_seeds (mwc.py:30-47);
  * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536, where NW = 4, 8 or 16 is the number of
  * waves per iterate workgroup (the table's size selects it): walkers, then the palette kernel's
- * states, then the output dither's.  stream = a hipStream_t to run everything on (single lane), or NULL:
+ * states, then the output dither's.  nslots: a multiple of 256 in [1024, 16384] — one temporal sample per
+ * slot — or 512 with NW = 8: the two halves of four waves of every workgroup then walk two temporal samples
+ * (1024 in all, 256 walkers each: the reference's geometry, cuburn/render.py:207), sharing one sort batch.  stream = a hipStream_t to run everything on (single lane), or NULL:
  * the context then owns two streams and alternates consecutive frames between them so that the
  * drain / filter / output work of frame k overlaps the iteration of frame k+1
  * (cuburn/render.py:432-433 swaps stream_a / stream_b the same way). */
@@ -165,9 +167,10 @@ int fl_genome_upload(fl_ctx *ctx, fl_genome *g, const float *times, const float 
 /* cuburn/render.py:289-307 RenderManager._interp: interp_palette_flat + interp_iter_params
  * for the frame window [ts, ts+td).  The reference evaluates 1024 temporal samples and runs one
  * block column per sample (grid (1024, n), render.py:343-346), so every sample gets the same number
- * of iterations.  Here the number of temporal samples equals the number of walker slots: block s
- * (s < nslots) is evaluated at ts + s*td/nslots and iterated by slot s, palette row r (of 64) at
- * ts + r*td/64 is used by slots [r*nslots/64, (r+1)*nslots/64) — equal weights for any nslots. */
+ * of iterations.  Here the number of temporal samples equals the number of walker slots (twice that
+ * for 512 slots of 8 waves): block s (s < n) is evaluated at ts + s*td/n and iterated by slot s (by half
+ * s % 2 of slot s / 2), palette row r (of 64) at ts + r*td/64 is used by slots
+ * [r*nslots/64, (r+1)*nslots/64) — equal weights for any nslots. */
 int fl_interp(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, float ts, float td);
 
 /* Accumulation back-ends for fl_iterate. */

@@ -1004,6 +1004,57 @@ def test_long_launch_log_beyond_4gb_binned_equals_atomic(monkeypatch, built):
     m.fb.free()
 
 
+def animated_cfg5():
+    """cfg5's twelve heavy xforms (more than the per-genome kernel keeps resident: records fetched per round, operand table in LDS)
+    with a moving xform, a moving offset and a turning camera, so that every temporal sample has its own parameter block."""
+    gnm, prof = configs.cfg5(samples=2 ** 26)
+    gnm['time'] = {'duration': 1, 'frame_width': 1.0}
+    gnm['camera'] = dict(gnm['camera'], rotation=[0.0, 15.0, 15.0, 15.0])
+    gnm['xforms']['03']['pre_affine']['angle'] = [30.0, 50.0, 80.0, 50.0]
+    gnm['xforms']['07']['pre_affine']['offset']['x'] = [-0.3, 0.5, 0.2, 0.5]
+    return gnm, dict(prof, frame_width=1.0, fps=24, duration=2)
+
+
+@pytest.mark.parametrize('rtc', ['1', '0'])
+@pytest.mark.parametrize('which,size', [('cfg3', (640, 360)), ('cfg3', (3840, 2160)), ('cfg5', (1280, 720))])
+def test_paired_halves_are_the_walkers_of_1024_four_wave_slots(which, size, rtc, monkeypatch, built):
+    """512 slots of 8 waves whose halves walk two temporal samples (render.py WIDE_FEW, iter.hip "Paired halves") are, walker for
+    walker, the 1024 slots of 4 waves of the reference's geometry: same seeds, same parameter block per walker (an ANIMATED genome:
+    every temporal sample has its own block), same point swap inside each half.  Counters, RNG states and walker points must agree
+    bit for bit, and so must the flushed density (cells of these flames fill up and drain into the float accumulator in an order
+    that is not reproducible even between two runs of ONE geometry, so the packed cells themselves are not compared; the colour
+    sums agree to float rounding) — direct atomics and the binned accumulate (whose batches now hold two samples' records), the
+    per-genome kernel and the interpreter."""
+    monkeypatch.setenv('FLAME_RTC', rtc)
+    gnm, prof = small(configs.cfg3, size[0], size[1]) if which == 'cfg3' else animated_cfg5()
+    prof = dict(prof, width=size[0], height=size[1])
+    out = {}
+    for tag, nw, nslots in (('four', 4, 1024), ('paired', 8, 512)):
+        if nw == 8:
+            monkeypatch.setenv('FLAME_NW', '8')
+        else:
+            monkeypatch.delenv('FLAME_NW', raising=False)
+        m = render.RenderManager(device=0, nslots=nslots, host_seed=46)
+        assert (m.fb.nw, m.fb.nslots, m.fb.nwalkers) == (nw, nslots, 1024 * 256 + 64 * 256 + 65536)
+        seeds = None
+        for mode in (0, 1):                                  # the binned run from the same RNG states as the direct one
+            res, _, rng, dim, seeds = run_device_model_gpu_only(m, gnm, prof, nrounds=21, fuse=5, mode=mode, seeds_in=seeds)
+            pts = m.fb.read('points', (1024 * 256, 4), np.float32)
+            _lib.check(_lib.load().fl_debug_flush(m.fb.ctx, dim.w, dim.h))
+            front = m.fb.read('front', (dim.ah * dim.astride, 4), np.float32)
+            out[tag, mode] = (res['ctr'].copy(), front, rng.copy(), pts.view(np.uint32).copy())
+        m.fb.free()
+    for mode in (0, 1):
+        (ca, fa, ra, pa), (cb, fb, rb, pb) = out['four', mode], out['paired', mode]
+        assert int(ca[0]) > 0.2 * 1024 * 256 * 21, ca
+        assert np.array_equal(ca[:3], cb[:3]), (mode, ca, cb)
+        assert np.array_equal(ra, rb) and np.array_equal(pa, pb), mode
+        assert np.array_equal(fa[:, 3], fb[:, 3]) and int(fa[:, 3].astype(np.float64).sum()) == int(ca[0]), mode
+        np.testing.assert_allclose(fa[:, :3], fb[:, :3], rtol=1e-5, atol=1e-4)
+    # binned == atomic in the paired geometry itself
+    assert np.array_equal(out['paired', 0][1][:, 3], out['paired', 1][1][:, 3])
+
+
 def run_device_model_gpu_only(mgr, gnm, prof, nrounds, fuse, mode, seeds_in=None):
     lib = _lib.load()
     if seeds_in is not None:
