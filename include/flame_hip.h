@@ -258,7 +258,7 @@ int fl_launch_stats(fl_ctx *ctx, uint32_t out[4]);
 enum {
     FL_BUF_FRONT = 0,   /* float4[nbins]  accumulator / filter result (render.py:44-48)  */
     FL_BUF_BACK = 1,    /* float4[nbins]                                                   */
-    FL_BUF_PARAMS = 2,  /* float[nslots * pstride] interpolated parameter blocks (one per slot) */
+    FL_BUF_PARAMS = 2,  /* float[ntemporal * pstride] interpolated parameter blocks (one per temporal sample = per slot; two per slot of 512 8-wave slots) */
     FL_BUF_PALETTE = 3, /* u64[FL_PAL_H * FL_PAL_W] packed palette (interp.py:409-433)     */
     FL_BUF_POINTS = 4,  /* float4[nwalkers] walker points (render.py:102-104)              */
     FL_BUF_SEEDS = 5,   /* fl_mwc[nwalkers]                                                */
