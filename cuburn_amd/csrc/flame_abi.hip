@@ -1177,7 +1177,7 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
     }
     std::vector<char> code;
     std::string err;
-    rc = rtc_compile(spec, nw, count != 0, acc, &code, &err);
+    rc = rtc_compile(spec, nw, (count & 1) != 0, acc, &code, &err, nullptr, (count & 2) != 0);
     if (log && log_bytes) { snprintf(log, log_bytes, "%s", rc ? err.c_str() : "ok"); }
     if (rc) return fail(rtc_available() ? FL_E_HIP : FL_E_UNSUPPORTED, "per-genome kernel did not compile", __FILE__, __LINE__);
     return (int)(code.size() > 0 ? FL_OK : FL_E_HIP);

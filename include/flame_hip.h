@@ -301,7 +301,8 @@ int fl_debug_shuffle(fl_ctx *ctx, uint32_t round, uint32_t *out256);
 int fl_debug_apply_xf(fl_ctx *ctx, fl_genome *g, uint32_t ts, int xfi, uint32_t n, float *xyzw, fl_mwc *rng);
 /* Compile (only) the iterate kernel specialised for a genome structure, as fl_iterate does on a genome's
  * first launch — the counterpart of cuburn/render.py:232-236 Renderer.compile.  Needs libhiprtc but no
- * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8 | 16, acc = 0 (atomic), 1 / 3 (binned narrow / wide). */
+ * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8 | 16, acc = 0 (atomic), 1 / 3 (binned narrow / wide);
+ * count: bit 0 = the sample counters, bit 1 = paired halves (nw = 8: two temporal samples per workgroup). */
 int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
                          char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */
