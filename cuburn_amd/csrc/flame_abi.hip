@@ -76,8 +76,8 @@ struct fl_ctx {
     int nlanes = 2, cur = 0;          // FLAME_LANES (1..4; default 2): consecutive frames go round the lanes
     Lane lanes[kMaxLanes];
     uint32_t nslots = 0, nwalkers = 0;
-    bool pair = false;                            // 512 slots of 8 waves: two temporal samples per workgroup (iter.hip "Paired halves")
-    uint32_t ntemporal() const { return pair ? nslots * 2u : nslots; }      // temporal samples = parameter blocks per frame (>= FL_NTEMPORAL)
+    uint32_t sub_log2 = 0;                        // 512 slots of 8 waves / 256 of 16: 2 / 4 temporal samples per workgroup (iter.hip "Sub-blocks of four waves")
+    uint32_t ntemporal() const { return nslots << sub_log2; }      // temporal samples = parameter blocks per frame (>= FL_NTEMPORAL)
     int nw = 4;                       // waves per iterate workgroup
     fl_mwc *d_rng = nullptr;          // [nwalkers]: walkers | palette rows (64*256) | output dither (FL_NOUT)
     float4 *d_points = nullptr;       // [nslots*NT]
@@ -109,7 +109,7 @@ struct fl_genome {
     uint64_t serial = 0;                    // unique per created genome (a lane remembers whose parameters its blocks hold)
     std::vector<int32_t> prog;
     IterSpec spec;                          // structure for the run-time specialised iterate kernel (rtc.hip)
-    hipFunction_t rtc_fn[4][2][4] = {};     // [nw 4 / 8 / 16 / 8 paired][count][acc] once compiled
+    hipFunction_t rtc_fn[5][2][4] = {};     // [nw 4 / 8 / 16 / 8 in halves / 16 in quarters][count][acc] once compiled
     unsigned rtc_epoch = 0;                 // module-cache epoch the handles above belong to
     bool rtc_failed = false;                // compile / load failed once: stay on the interpreter kernel
     uint32_t nops = 0, nrows = 0, pstride = 0;
@@ -221,8 +221,8 @@ static bool env_on(const char *name) { const char *e = getenv(name); return e &&
 int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds, uint32_t nslots, fl_ctx **out)
 {
     REQUIRE(out && seeds, "null argument");
-    REQUIRE((nslots >= FL_NTEMPORAL || nslots == FL_NTEMPORAL / 2) && nslots % 256 == 0 && nslots <= 16384,
-            "nslots must be a multiple of 256 in [1024, 16384] (or 512 slots of 8 waves: two temporal samples per workgroup)");
+    REQUIRE((nslots >= FL_NTEMPORAL || nslots == FL_NTEMPORAL / 2 || nslots == FL_NTEMPORAL / 4) && nslots % 256 == 0 && nslots <= 16384,
+            "nslots must be a multiple of 256 in [1024, 16384] (or 512 slots of 8 waves / 256 of 16: two / four temporal samples per workgroup)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FL_E_NODEV, "no HIP device", __FILE__, __LINE__);
     REQUIRE(device >= 0 && device < ndev, "bad device index");
@@ -244,10 +244,10 @@ int fl_ctx_create(int device, void *stream, const fl_mwc *seeds, uint32_t nseeds
     fl_ctx *c = new fl_ctx;
     c->device = device;
     c->nw = nw;
-    if (nslots < FL_NTEMPORAL && nw != 8)
-        return fail(FL_E_INVAL, "512 slots need 8-wave workgroups (two temporal samples each: 1024 in all)", __FILE__, __LINE__);
+    if (nslots < FL_NTEMPORAL && (uint32_t)nw * nslots != 4u * FL_NTEMPORAL)
+        return fail(FL_E_INVAL, "512 slots need 8-wave workgroups, 256 slots 16-wave ones (a temporal sample per four waves: 1024 in all)", __FILE__, __LINE__);
     c->nslots = nslots;
-    c->pair = nslots < FL_NTEMPORAL;
+    c->sub_log2 = nslots >= FL_NTEMPORAL ? 0u : nw == 8 ? 1u : 2u;
     c->nwalkers = nslots * (uint32_t)nw * 64 + FL_PAL_H * 256 + FL_NOUT;
     if (const char *e = getenv("FLAME_LANES")) { const int v = atoi(e); c->nlanes = v >= 1 && v <= fl_ctx::kMaxLanes ? v : 2; }
     if (const char *e = getenv("FLAME_BIN_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= FL_BIN_R_MAX) c->bin_rounds = (uint32_t)v; }
@@ -526,7 +526,7 @@ int fl_interp(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, float ts, float t
     // at ts + s*td/nslots, so that every temporal sample receives the same number of iterations
     // whatever the slot count (the reference: one block column per each of its 1024 temporal
     // samples, cuburn/render.py:303-307,343-346; cuburn/code/iter.py:165,184).
-    const size_t need = (size_t)c->ntemporal() * g->pstride;     // (paired 8-wave workgroups: two blocks per slot)
+    const size_t need = (size_t)c->ntemporal() * g->pstride;     // (workgroups in sub-blocks: two or four blocks per slot)
     if (need > L(c).params_floats) {
         HIPCHK(hipStreamSynchronize(L(c).stream));
         hipFree(L(c).d_params); L(c).d_params = nullptr; L(c).params_floats = 0;
@@ -615,10 +615,10 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
     if (c->use_rtc && !g->rtc_failed && kacc != 2) {
         const unsigned ep = rtc_epoch();
         if (g->rtc_epoch != ep) { memset(g->rtc_fn, 0, sizeof g->rtc_fn); g->rtc_epoch = ep; }     // the module cache was flushed
-        hipFunction_t &slot = g->rtc_fn[c->pair ? 3 : c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
+        hipFunction_t &slot = g->rtc_fn[c->sub_log2 ? 2 + c->sub_log2 : c->nw == 16 ? 2 : c->nw == 8][count ? 1 : 0][kacc];
         if (!slot) {
             std::string err;
-            if (rtc_iter_kernel(c->device, g->spec, c->nw, c->nslots, count, kacc, &slot, &err, c->pair)) {
+            if (rtc_iter_kernel(c->device, g->spec, c->nw, c->nslots, count, kacc, &slot, &err, c->sub_log2)) {
                 g->rtc_failed = true;
                 slot = nullptr;
                 fprintf(stderr, "libflame_hip: per-genome kernel not available (%s); using the interpreter kernel\n", err.c_str());
@@ -631,12 +631,12 @@ static int do_iter_launch(fl_ctx *c, fl_genome *g, const fl_dim &d, uint32_t nro
         launch_iter_fn(L(c).stream, fn, c->nw, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                        L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                        tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
-                       e ? e->a : nullptr, e ? e->b : nullptr, c->pair);
+                       e ? e->a : nullptr, e ? e->b : nullptr, c->sub_log2);
     else
     launch_iter(L(c).stream, c->nw, count, kacc, c->nslots, g->d_prog, L(c).d_params, L(c).d_palette, c->d_rng, c->d_points,
                 L(c).d_hot, L(c).d_atom, (float *)L(c).d_front, c->d_counters, d.astride, d.ah, c->round_counter, nrounds, fuse,
                 tiles_x, nbins, c->bin_rounds, nbatch_total, L(c).d_log[buf], L(c).d_dir[buf],
-                e ? e->a : nullptr, e ? e->b : nullptr, c->pair);
+                e ? e->a : nullptr, e ? e->b : nullptr, c->sub_log2);
     c->round_counter += nrounds;
     HIPCHK(hipGetLastError());
     if (acc == FL_ACCUM_BINNED) {
@@ -696,16 +696,20 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     // + flush of each launch go to the lane's aux stream, with two log / directory sets: launch k+1
     // iterates while launch k drains.  (Both kernels want the whole chip, so this buys little —
     // DESIGN.md §4.1 — but it costs nothing and hides the drains' launch gaps.)
-    auto launches_with = [rounds](uint64_t cap_) { uint32_t nl = 0; for (uint64_t r = rounds, b = 4; r; b += b / 2) { r -= std::min(std::min(r, b * 256), cap_); ++nl; } return nl; };
+    // (workgroups in sub-blocks have a half or a quarter of the walkers of their plain geometry: their rounds count double / fourfold
+    // for the same samples per launch, i.e. the same log, flush schedule and number of launches)
+    const uint64_t unit = 256ull << c->sub_log2;
+    auto launches_with = [rounds, unit](uint64_t cap_) { uint32_t nl = 0; for (uint64_t r = rounds, b = 4; r; b += b / 2) { r -= std::min(std::min(r, b * unit), cap_); ++nl; } return nl; };
+    const uint64_t cap_short = (uint64_t)FL_BIN_MAX_ROUNDS << c->sub_log2, cap_long = (uint64_t)FL_BIN_MAX_ROUNDS_LONG << c->sub_log2;
     const uint64_t cap = accum_mode != FL_ACCUM_BINNED ? ~0ull : c->launch_rounds ? c->launch_rounds :
-                         launches_with(FL_BIN_MAX_ROUNDS_LONG) < launches_with(FL_BIN_MAX_ROUNDS) ? FL_BIN_MAX_ROUNDS_LONG : FL_BIN_MAX_ROUNDS;
+                         launches_with(cap_long) < launches_with(cap_short) ? cap_long : cap_short;
     const uint32_t nlaunch = launches_with(cap);
     const bool pipelined = accum_mode == FL_ACCUM_BINNED && nlaunch > 1 && !c->env_no_intra;
     hipStream_t drain = pipelined ? L(c).aux : L(c).stream;
     uint64_t batch = 4;
     uint32_t k = 0;
     while (rounds) {
-        const uint64_t n = std::min(std::min(rounds, batch * 256), cap);
+        const uint64_t n = std::min(std::min(rounds, batch * unit), cap);
         const uint32_t f = k == 0 ? fuse : 0;
         const int buf = pipelined ? (int)(k & 1u) : 0;
         // the drains of launch k-2 read this log / directory set: they must be done before it is rewritten
@@ -1177,7 +1181,7 @@ int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops
     }
     std::vector<char> code;
     std::string err;
-    rc = rtc_compile(spec, nw, (count & 1) != 0, acc, &code, &err, nullptr, (count & 2) != 0);
+    rc = rtc_compile(spec, nw, (count & 1) != 0, acc, &code, &err, nullptr, (count & 2) == 0 ? 0u : nw == 8 ? 1u : nw == 16 ? 2u : 0u);
     if (log && log_bytes) { snprintf(log, log_bytes, "%s", rc ? err.c_str() : "ok"); }
     if (rc) return fail(rtc_available() ? FL_E_HIP : FL_E_UNSUPPORTED, "per-genome kernel did not compile", __FILE__, __LINE__);
     return (int)(code.size() > 0 ? FL_OK : FL_E_HIP);

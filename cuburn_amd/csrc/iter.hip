@@ -277,7 +277,7 @@ struct BinGeom {
     uint32_t nbins;          // number of tiles B (<= FL_MAX_BINS)
     uint32_t rounds;         // R: write-enabled rounds per batch
     uint32_t nbatch_total;   // batches of this launch = nslots * batches per slot
-    uint32_t pair;           // 8-wave workgroups only: 1 = the two halves of four waves walk two temporal samples (2 * slot, 2 * slot + 1), see iter_body
+    uint32_t sub_log2;       // 0: a temporal sample per workgroup; 1 (8 waves) / 2 (16 waves): every four waves walk their own sample (2 or 4 per slot), see iter_body
 };
 // log: [nbatch_total * R * NT] sorted records; dir: [B][nbatch_total] (first record << 16) | count.
 // They are separate __restrict__ kernel arguments: as members of the struct the compiler has to
@@ -334,19 +334,21 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     uint32_t *my_cnt = cnt + ((threadIdx.x & 63u) % SETS) * CNTW;
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // Paired halves (8-wave workgroups of frames with few samples, round 5): the reference walks 256 threads per temporal sample
-    // (cuburn/render.py:207, 1024 samples); an 8-wave workgroup per sample walks 512, i.e. twice the reference's un-plotted fuse
-    // rounds per frame.  Paired, waves 0-3 walk sample 2 * slot and waves 4-7 sample 2 * slot + 1 — walkers, RNG streams, point swap
-    // and parameter blocks exactly those of 1024 four-wave slots (same results, bit for bit) — and share one sort batch, which is
-    // what the 8-wave geometry is for.  (The wave number on the scalar side: the parameter block must stay a scalar base.)
+    // Sub-blocks of four waves ("paired halves" of 8-wave workgroups, quarters of 16-wave ones; round 5): the reference walks 256
+    // threads per temporal sample (cuburn/render.py:207, 1024 samples); an 8- or 16-wave workgroup per sample walks 512 or 1024,
+    // i.e. two or four times the reference's un-plotted fuse rounds per frame.  With sub-blocks, waves 4q .. 4q + 3 walk sample
+    // (NW / 4) * slot + q — walkers, RNG streams, point swap and parameter blocks exactly those of 1024 four-wave slots (same
+    // results, bit for bit) — and the whole workgroup shares one sort batch, which is what the large workgroups are for.
+    // (The wave number on the scalar side: the parameter block must stay a scalar base.)
 #ifdef FL_RTC
-    constexpr bool kPairSpec = FL_SPEC_PAIR != 0;
+    constexpr uint32_t kSubSpec = FL_SPEC_SUB_LOG2;
 #else
-    constexpr bool kPairSpec = false;
+    constexpr uint32_t kSubSpec = 0;
 #endif
-    const bool pair = NW == 8 && (SPEC ? kPairSpec : bg.pair != 0u);
-    const uint32_t half = pair ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 2)) : 0u;
-    const uint32_t slot = blockIdx.x, ts = pair ? slot * 2u + half : slot, prow = slot * FL_PAL_H / gridDim.x;
+    const uint32_t sub_log2 = NW == 4 ? 0u : SPEC ? kSubSpec : bg.sub_log2;      // 0, or log2(NW / 4)
+    const bool pair = sub_log2 != 0u;
+    const uint32_t half = pair ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 2)) : 0u;      // which sub-block
+    const uint32_t slot = blockIdx.x, ts = pair ? (slot << sub_log2) + half : slot, prow = slot * FL_PAL_H / gridDim.x;
 #ifdef FL_RTC
     const int nxf = SPEC ? FL_SPEC_NXF : prog[1], has_final = SPEC ? FL_SPEC_FINAL : prog[2], pstride = SPEC ? FL_SPEC_PSTRIDE : prog[3];
     const int cdf_off = SPEC ? FL_SPEC_CDF_OFF : prog[4], xf_off = SPEC ? FL_SPEC_XF_OFF : prog[5];
@@ -400,7 +402,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     }
     // swap destinations of this and the next two rounds (phase = round % 3), rotated every round
     auto swap_dest = [&](const uint32_t phase) -> uint32_t {
-        return pair ? (w & 4u) * 64u + shuffle_dest<4>(w & 3u, l, phase) : shuffle_dest<NW>(w, l, phase);      // paired: within the half
+        return pair ? (w & ~3u) * 64u + shuffle_dest<4>(w & 3u, l, phase) : shuffle_dest<NW>(w, l, phase);      // sub-blocks: within the four waves
     };
     uint32_t rot0 = swap_dest(round0 % 3u), rot1 = swap_dest((round0 + 1u) % 3u), rot2 = swap_dest((round0 + 2u) % 3u);
     uint32_t n_acc = 0, n_oob = 0, n_drop = 0, n_spill = 0;
@@ -862,13 +864,13 @@ k_flush(u64 *__restrict__ atom, float4 *__restrict__ out, uint32_t *__restrict__
 }
 
 // ---- host-side launchers --------------------------------------------------------------------
-static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins, bool pair)
+static size_t iter_lds_bytes(int nw, int acc, uint32_t rounds, uint32_t nbins, uint32_t sub_log2)
 {
     size_t nt = (size_t)nw * 64, b = 2 * 3 * nt * 4;
     if (acc == 1 || acc == 3) b += (size_t)rounds * nt * (acc == 3 ? 6 : 4) + (nw == 4 ? FL_CNT_SETS : FL_CNT_SETS_BIG) * (size_t)((nbins + 1 + 3) & ~3u) * 4 + 16
              + 128 * 4;      // chunk totals (only the all-waves scan uses them; the operand table sits behind them either way)
     else b += FL_PAL_W * 8;
-    return b + FL_XTAB_BYTES * (pair ? 2 : 1);      // (paired halves: an operand table per half)
+    return b + ((size_t)FL_XTAB_BYTES << sub_log2);      // (sub-blocks: an operand table each)
 }
 
 void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
@@ -876,10 +878,11 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
                  uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                  uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
-                 uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, bool pair)
+                 uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t sub_log2)
 {
-    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, pair && nw == 8 ? 1u : 0u};
-    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins, pair && nw == 8);
+    if (sub_log2 != 0u && (4 << sub_log2) != nw) abort();      // sub-blocks are four waves
+    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, sub_log2};
+    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins, sub_log2);
 #define LAUNCH(NW, C, A) do { \
         static unsigned long long attr_done = 0; \
         ensure_max_dynamic_lds((const void *)k_iter<NW, C, A>, attr_done); \
@@ -900,10 +903,11 @@ void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t 
                     float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
                     uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                     uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
-                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, bool pair)
+                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t sub_log2)
 {
-    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, pair && nw == 8 ? 1u : 0u};
-    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins, pair && nw == 8);
+    if (sub_log2 != 0u && (4 << sub_log2) != nw) abort();      // sub-blocks are four waves
+    BinGeom bg = {tiles_x, nbins, rounds_per_batch, nbatch_total, sub_log2};
+    const size_t lds = iter_lds_bytes(nw, acc, rounds_per_batch, nbins, sub_log2);
     void *args[] = {&prog, &params, &palette, &rng, &points, &hot, &atom, &out4, &counters, &astride, &aheight,
                     &round0, &nrounds, &fuse, &bg, &log, &dir};
     // (no hipFuncSetAttribute here: that API takes a host function pointer, not a module function; module launches

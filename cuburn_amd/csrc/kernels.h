@@ -24,7 +24,7 @@ void launch_iter(hipStream_t st, int nw, bool count, int acc, uint32_t nslots,
                  uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                  uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
                  uint32_t *log, uint32_t *dir,
-                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool pair = false);      // pair: 8-wave workgroups of two temporal samples (iter_body)
+                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, uint32_t sub_log2 = 0);      // sub_log2: 8- / 16-wave workgroups of 2 / 4 temporal samples (iter_body)
 void launch_flush(hipStream_t st, u64 *atom, float4 *out, uint32_t *hot, uint32_t nbins, bool use_hot);
 void launch_clear_frame(hipStream_t st, float4 *front, u64 *atom, uint32_t *hot, u64 *counters, float4 *points,
                         uint32_t nbins, uint32_t npoints);      // npoints = 0: the walkers are left alone
@@ -42,15 +42,15 @@ struct IterSpec {
 };
 bool rtc_available();
 unsigned rtc_epoch();      // changes when cached modules were unloaded: function handles obtained before are void
-int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt = nullptr, bool pair = false);
-int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err, bool pair = false);
+int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt = nullptr, uint32_t sub_log2 = 0);
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err, uint32_t sub_log2 = 0);
 // launch_iter through a run-time compiled kernel (same arguments)
 void launch_iter_fn(hipStream_t st, hipFunction_t fn, int nw, int acc, uint32_t nslots,
                     const int32_t *prog, const float *params, const u64 *palette, fl_mwc *rng,
                     float4 *points, const uint32_t *hot, u64 *atom, float *out4, u64 *counters,
                     uint32_t astride, uint32_t aheight, uint32_t round0, uint32_t nrounds, uint32_t fuse,
                     uint32_t tiles_x, uint32_t nbins, uint32_t rounds_per_batch, uint32_t nbatch_total,
-                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, bool pair = false);
+                    uint32_t *log, uint32_t *dir, hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t sub_log2 = 0);
 
 // binned.hip
 void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir, const u64 *palette,

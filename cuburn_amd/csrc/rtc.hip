@@ -64,7 +64,7 @@ std::map<std::string, Entry> g_cache;           // key: device + generated heade
 unsigned g_epoch = 1;                           // bumped whenever modules are unloaded: handles held by callers expire
 const size_t kMaxModules = 64;                  // (the reference keeps 20, render.py:229)
 
-std::string spec_header(const IterSpec &s, int nw, bool count, int acc, bool pair)
+std::string spec_header(const IterSpec &s, int nw, bool count, int acc, uint32_t sub_log2)
 {
     const int nrec = s.nxf + s.has_final;
     int maxv = 1;
@@ -75,7 +75,7 @@ std::string spec_header(const IterSpec &s, int nw, bool count, int acc, bool pai
     DEF("FL_SPEC_NXF", s.nxf); DEF("FL_SPEC_FINAL", s.has_final); DEF("FL_SPEC_PSTRIDE", s.pstride);
     DEF("FL_SPEC_CDF_OFF", s.cdf_off); DEF("FL_SPEC_XF_OFF", s.xf_off); DEF("FL_SPEC_XF_STRIDE", s.xf_stride);
     DEF("FL_SPEC_VAR_STRIDE", s.var_stride); DEF("FL_SPEC_NW", nw); DEF("FL_SPEC_COUNT", count ? 1 : 0); DEF("FL_SPEC_ACC", acc);
-    DEF("FL_SPEC_PAIR", pair && nw == 8 ? 1 : 0);
+    DEF("FL_SPEC_SUB_LOG2", sub_log2 != 0u && (4 << sub_log2) == nw ? (int)sub_log2 : 0);
 #undef DEF
     h += "constexpr int kSpecNvar[] = {";
     for (int i = 0; i < nrec; ++i) h += std::to_string(s.nvar[i]) + ",";
@@ -96,11 +96,11 @@ std::string spec_header(const IterSpec &s, int nw, bool count, int acc, bool pai
 
 bool rtc_available() { return api().ok; }
 
-int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt, bool pair)
+int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<char> *code, std::string *err, const char *extra_opt, uint32_t sub_log2)
 {
     const Api &a = api();
     if (!a.ok) { *err = "libhiprtc not found"; return -1; }
-    const std::string header = spec_header(spec, nw, count, acc, pair);
+    const std::string header = spec_header(spec, nw, count, acc, sub_log2);
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {rtc_src_variations, rtc_src_device, rtc_src_abi, header.c_str()};
     const char *hdr_name[] = {"variations.h", "flame_device.h", "flame_hip.h", "flame_spec.h"};
@@ -176,14 +176,14 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 
 unsigned rtc_epoch() { std::lock_guard<std::mutex> lock(g_mu); return g_epoch; }
 
-int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err, bool pair)
+int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, bool count, int acc, hipFunction_t *fn, std::string *err, uint32_t sub_log2)
 {
     // vector registers a four-wave kernel may use before a workgroup per CU is lost: every slot is resident at once, nslots * 4
     // waves over 1024 SIMDs of 512 registers each — 128 at the 1024 slots of frames of up to 2^28 samples (four waves per SIMD),
     // 80 at 1536 (six; the allocation granule is 8).  Other geometries are bounded by LDS, not registers: no limit.
     const uint32_t wps = (nslots * 4u + 1023u) / 1024u;
     const int reg_limit = nw == 4 && wps >= 1u && wps <= 8u ? (int)(512u / wps / 8u * 8u) : 0;
-    const std::string key = std::to_string(device) + "|" + std::to_string(reg_limit) + "|" + spec_header(spec, nw, count, acc, pair);
+    const std::string key = std::to_string(device) + "|" + std::to_string(reg_limit) + "|" + spec_header(spec, nw, count, acc, sub_log2);
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn = it->second.fn; return 0; }
@@ -196,7 +196,7 @@ int rtc_iter_kernel(int device, const IterSpec &spec, int nw, uint32_t nslots, b
     Entry first; bool have_first = false;
     for (int b = 0; b < 4; ++b) {
         std::vector<char> code;
-        if (rtc_compile(spec, nw, count, acc, &code, err, budgets[b], pair)) { if (have_first) break; return -1; }
+        if (rtc_compile(spec, nw, count, acc, &code, err, budgets[b], sub_log2)) { if (have_first) break; return -1; }
         Entry t;
         if (hipModuleLoadData(&t.mod, code.data()) != hipSuccess) { (void)hipGetLastError(); *err = "hipModuleLoadData failed"; if (have_first) break; return -1; }
         if (hipModuleGetFunction(&t.fn, t.mod, "k_iter_spec") != hipSuccess) {

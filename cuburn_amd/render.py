@@ -101,8 +101,10 @@ class Framebuffers(object):
     NARROW_FEW = (4, 1024)
     # The same for the 8-wave geometry (round 5): 512 slots whose two halves of four waves walk two temporal samples — the
     # reference's 1024 samples x 256 threads exactly, bit for bit the walkers of NARROW_FEW, sharing 8192-record sort batches
-    # (csrc/iter.hip "Paired halves").  1024 slots of 8 waves walk 512 threads per sample: twice the un-plotted rounds.
+    # (csrc/iter.hip "Sub-blocks of four waves").  1024 slots of 8 waves walk 512 threads per sample: twice the un-plotted rounds.
     WIDE_FEW = (8, 512)
+    HUGE_FEW = (16, 256)        # the same above 4K: four temporal samples per 16-wave workgroup (8K frames of 2^28 samples: iterate -19 %,
+                                # frame -4.4 %; with 2^32 samples the frame gains 1.8 % but the iterate kernel alone loses 10 %: not taken there)
     FEW_SAMPLES = 2 ** 28
     WIDE_FROM_TILES = 1024
     HUGE_FROM_TILES = 2047      # above 4K (where the accumulate switches to 256x64 tiles): 16-wave workgroups,
@@ -124,7 +126,7 @@ class Framebuffers(object):
     nw = property(lambda self: self._cfg[0])             # waves per iterate workgroup
     nslots = property(lambda self: self._cfg[1])
     nthreads = property(lambda self: self._cfg[0] * 64)
-    ntemporal = property(lambda self: self.nslots * 2 if self._cfg == self.WIDE_FEW else self.nslots)     # temporal samples per frame
+    ntemporal = property(lambda self: max(self.nslots, 1024))     # temporal samples per frame (512 x 8 / 256 x 16 waves: a sample per four waves)
     nwalkers = property(lambda self: self.nslots * self.nthreads + 64 * 256 + self.nout)
 
     @property
@@ -179,6 +181,11 @@ class Framebuffers(object):
                 if nsamples is not None:
                     want = self.WIDE_FEW if nsamples <= self.FEW_SAMPLES else self.WIDE
                 elif self._cfg in (self.WIDE, self.WIDE_FEW):
+                    want = self._cfg
+            elif want == self.HUGE:
+                if nsamples is not None:
+                    want = self.HUGE_FEW if nsamples <= self.FEW_SAMPLES else self.HUGE
+                elif self._cfg in (self.HUGE, self.HUGE_FEW):
                     want = self._cfg
             if want != self._cfg:
                 self._drop_ctx()

@@ -61,7 +61,7 @@ typedef struct fl_mwc {
  */
 #define FL_KNOTS 32
 #define FL_NTEMPORAL 1024   /* cuburn/render.py:207 ntemporal_samples = the minimum number of temporal samples here: one per
-                               walker slot (fl_ctx_create nslots >= 1024), or two per slot of 512 8-wave slots, see fl_interp */
+                               walker slot (fl_ctx_create nslots >= 1024), or two / four per slot of 512 8-wave / 256 16-wave slots, see fl_interp */
 #define FL_PAL_W 256        /* cuburn/render.py:201-202 palette surface 256 x 64 */
 #define FL_PAL_H 64
 #define FL_GUTTER 12        /* cuburn/render.py:77 */
@@ -143,8 +143,8 @@ void fl_calc_dim(uint32_t w, uint32_t h, fl_dim *out);
  * nseeds must be nslots * 64 * NW + FL_PAL_H * 256 + 65536, where NW = 4, 8 or 16 is the number of
  * waves per iterate workgroup (the table's size selects it): walkers, then the palette kernel's
  * states, then the output dither's.  nslots: a multiple of 256 in [1024, 16384] — one temporal sample per
- * slot — or 512 with NW = 8: the two halves of four waves of every workgroup then walk two temporal samples
- * (1024 in all, 256 walkers each: the reference's geometry, cuburn/render.py:207), sharing one sort batch.  stream = a hipStream_t to run everything on (single lane), or NULL:
+ * slot — or 512 with NW = 8 / 256 with NW = 16: every four waves of a workgroup then walk a temporal sample of
+ * their own (1024 in all, 256 walkers each: the reference's geometry, cuburn/render.py:207), sharing one sort batch.  stream = a hipStream_t to run everything on (single lane), or NULL:
  * the context then owns two streams and alternates consecutive frames between them so that the
  * drain / filter / output work of frame k overlaps the iteration of frame k+1
  * (cuburn/render.py:432-433 swaps stream_a / stream_b the same way). */
@@ -168,8 +168,8 @@ int fl_genome_upload(fl_ctx *ctx, fl_genome *g, const float *times, const float 
  * for the frame window [ts, ts+td).  The reference evaluates 1024 temporal samples and runs one
  * block column per sample (grid (1024, n), render.py:343-346), so every sample gets the same number
  * of iterations.  Here the number of temporal samples equals the number of walker slots (twice that
- * for 512 slots of 8 waves): block s (s < n) is evaluated at ts + s*td/n and iterated by slot s (by half
- * s % 2 of slot s / 2), palette row r (of 64) at ts + r*td/64 is used by slots
+ * / four times that for 512 slots of 8 waves / 256 of 16): block s (s < n) is evaluated at ts + s*td/n and iterated
+ * by slot s (by sub-block s % k of slot s / k), palette row r (of 64) at ts + r*td/64 is used by slots
  * [r*nslots/64, (r+1)*nslots/64) — equal weights for any nslots. */
 int fl_interp(fl_ctx *ctx, fl_genome *g, uint32_t w, uint32_t h, float ts, float td);
 
@@ -258,7 +258,7 @@ int fl_launch_stats(fl_ctx *ctx, uint32_t out[4]);
 enum {
     FL_BUF_FRONT = 0,   /* float4[nbins]  accumulator / filter result (render.py:44-48)  */
     FL_BUF_BACK = 1,    /* float4[nbins]                                                   */
-    FL_BUF_PARAMS = 2,  /* float[ntemporal * pstride] interpolated parameter blocks (one per temporal sample = per slot; two per slot of 512 8-wave slots) */
+    FL_BUF_PARAMS = 2,  /* float[ntemporal * pstride] interpolated parameter blocks (one per temporal sample = per slot; two / four per slot of 512 8-wave / 256 16-wave slots) */
     FL_BUF_PALETTE = 3, /* u64[FL_PAL_H * FL_PAL_W] packed palette (interp.py:409-433)     */
     FL_BUF_POINTS = 4,  /* float4[nwalkers] walker points (render.py:102-104)              */
     FL_BUF_SEEDS = 5,   /* fl_mwc[nwalkers]                                                */
@@ -302,7 +302,7 @@ int fl_debug_apply_xf(fl_ctx *ctx, fl_genome *g, uint32_t ts, int xfi, uint32_t 
 /* Compile (only) the iterate kernel specialised for a genome structure, as fl_iterate does on a genome's
  * first launch — the counterpart of cuburn/render.py:232-236 Renderer.compile.  Needs libhiprtc but no
  * GPU; FL_E_UNSUPPORTED if hipRTC is not installed.  nw = 4 | 8 | 16, acc = 0 (atomic), 1 / 3 (binned narrow / wide);
- * count: bit 0 = the sample counters, bit 1 = paired halves (nw = 8: two temporal samples per workgroup). */
+ * count: bit 0 = the sample counters, bit 1 = a temporal sample per four waves (nw = 8 / 16: two / four per workgroup). */
 int fl_rtc_compile_check(const int32_t *prog, uint32_t nprog, const int32_t *ops, uint32_t nops, int nw, int count, int acc,
                          char *log, size_t log_bytes);
 /* Counters of the last iterate: accepted (written) samples, out-of-frame, roulette-dropped, spills. */

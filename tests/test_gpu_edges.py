@@ -281,7 +281,7 @@ def test_walker_geometry_follows_image_size():
     them for frames of up to 2^28 samples, 1536 above, decided per frame from its sample count (the same
     (seed, frame) renders the same whatever the context rendered before) —
     8-wave slots from ~1440p up — 512 whose halves walk two temporal samples for frames of up to 2^28 samples, 1024 above —
-    and 1024 x 16-wave slots above 4K (the native context is re-created on the switch, genome handles follow)."""
+    and 16-wave slots above 4K — 256 in quarters / 1024 — (the native context is re-created on the switch, genome handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)
     assert (m.fb.nw, m.fb.nslots) == (4, 1536)
     gnm, prof = configs.cfg2(samples=2 ** 24)
@@ -295,10 +295,10 @@ def test_walker_geometry_follows_image_size():
     evt, a1 = m.queue_frame(rdr_s, gnm, small, 0.5); evt.synchronize()        # same class of frame: no further switch
     assert m.fb.generation == gen0
     evt, b = m.queue_frame(rdr_b, gnm, big, 0.5); evt.synchronize()
-    assert (m.fb.nw, m.fb.nslots) == (16, 1024) and m.fb.generation == gen0 + 1
+    assert (m.fb.nw, m.fb.nslots, m.fb.ntemporal) == (16, 256, 1024) and m.fb.generation == gen0 + 1      # few samples: a sample per four waves
     b = np.array(b)
     assert b.shape == (4320, 7680, 4) and b[..., 3].max() > 0
-    assert m.last_nsamples % (1024 * 1024) == 0
+    assert m.last_nsamples % (256 * 1024) == 0
     mid = profile.wrap(dict(prof, width=3840, height=2160, spp=2 ** 25 / (3840.0 * 2160.0)), gnm)
     evt, c = m.queue_frame(render.Renderer(gnm, mid), gnm, mid, 0.5); evt.synchronize()
     assert (m.fb.nw, m.fb.nslots, m.fb.ntemporal) == (8, 512, 1024) and m.fb.generation == gen0 + 2 and np.array(c)[..., 3].max() > 0

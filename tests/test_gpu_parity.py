@@ -1016,10 +1016,11 @@ def animated_cfg5():
 
 
 @pytest.mark.parametrize('rtc', ['1', '0'])
+@pytest.mark.parametrize('geom', [(8, 512), (16, 256)])
 @pytest.mark.parametrize('which,size', [('cfg3', (640, 360)), ('cfg3', (3840, 2160)), ('cfg5', (1280, 720))])
-def test_paired_halves_are_the_walkers_of_1024_four_wave_slots(which, size, rtc, monkeypatch, built):
-    """512 slots of 8 waves whose halves walk two temporal samples (render.py WIDE_FEW, iter.hip "Paired halves") are, walker for
-    walker, the 1024 slots of 4 waves of the reference's geometry: same seeds, same parameter block per walker (an ANIMATED genome:
+def test_paired_halves_are_the_walkers_of_1024_four_wave_slots(which, size, geom, rtc, monkeypatch, built):
+    """512 slots of 8 waves whose halves — and 256 slots of 16 waves whose quarters — walk their own temporal samples (render.py
+    WIDE_FEW / HUGE_FEW, iter.hip "Sub-blocks of four waves") are, walker for walker, the 1024 slots of 4 waves of the reference's geometry: same seeds, same parameter block per walker (an ANIMATED genome:
     every temporal sample has its own block), same point swap inside each half.  Counters, RNG states and walker points must agree
     bit for bit, and so must the flushed density (cells of these flames fill up and drain into the float accumulator in an order
     that is not reproducible even between two runs of ONE geometry, so the packed cells themselves are not compared; the colour
@@ -1029,9 +1030,9 @@ def test_paired_halves_are_the_walkers_of_1024_four_wave_slots(which, size, rtc,
     gnm, prof = small(configs.cfg3, size[0], size[1]) if which == 'cfg3' else animated_cfg5()
     prof = dict(prof, width=size[0], height=size[1])
     out = {}
-    for tag, nw, nslots in (('four', 4, 1024), ('paired', 8, 512)):
-        if nw == 8:
-            monkeypatch.setenv('FLAME_NW', '8')
+    for tag, nw, nslots in (('four', 4, 1024), ('paired',) + geom):
+        if nw != 4:
+            monkeypatch.setenv('FLAME_NW', str(nw))
         else:
             monkeypatch.delenv('FLAME_NW', raising=False)
         m = render.RenderManager(device=0, nslots=nslots, host_seed=46)
