@@ -434,7 +434,7 @@ def main():
                                     '2^28 samples/frame, filters yuv+bilateral+logscale+colorclip, rgba8 out') if args.config == 'cfg2'
                        else 'BASELINE %s (diagnostic run, not the headline workload): %dx%d, %d xforms, %d samples/frame'
                             % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
-                       'walker_waves': mgr.fb.nw, 'walker_slots': mgr.fb.nslots,
+                       'walker_waves': mgr.fb.nw, 'walker_slots': mgr.fb.nslots, 'temporal_samples': mgr.fb.ntemporal,
                        'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step,
                        'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round(big_ms, 4),
                                         'overlap_ms_per_frame': round(big_ms - elapsed / args.steps * 1e3, 4),
