@@ -105,14 +105,34 @@ __device__ __forceinline__ void apply_xf(const XfHead &h, const float *__restric
 // variations, whether it has a post affine, and its variation numbers in order.
 #include "flame_spec.h"
 
+// FL_EARLY_TAIL (round 5): kernels whose records are fetched per round ask for the ten words behind the record's head — the first
+// variation's parameters and the second one's number and weight — a round ahead, together with the head, instead of at the top of the
+// xform's own block ~10 instructions before their use: a scalar load there was a scalar-cache latency per round that four waves per
+// SIMD only partly cover, and every lgkmcnt wait of the block waited for it.  cfg4 (eight xforms of two variations): k_iter_spec
+// 1.089 -> 1.019 ms, 30 -> 13 scalar loads and 40 -> 30 lgkmcnt waits in cfg5's loop (profiles/r05_early_tail.txt).  Same values from
+// the same words: bit-identical (the per-genome kernel is held to the interpreter in tests/).  -DFL_EARLY_TAIL=0: on demand, as before.
+#ifndef FL_EARLY_TAIL
+#define FL_EARLY_TAIL 1
+#endif
+constexpr int kTailFirst = FL_XF_HDR + 2, kTailWords = 10;
+struct XfTail { float w[kTailWords]; };
+// a variation's parameters: word `base + i` of the record, from the registers where the tail holds it
+struct VTail {
+    const float *__restrict__ p; const XfTail *t; int base;
+    __device__ __forceinline__ float operator[](int i) const {
+        const int wd = base + i;
+        return (FL_EARLY_TAIL && t && wd >= kTailFirst && wd < kTailFirst + kTailWords) ? t->w[wd - kTailFirst] : p[wd];
+    }
+};
 template <int I, int J>
 __device__ __forceinline__ void spec_variations(const float *__restrict__ xf, float w0, float &tx, float &ty,
-                                                float &ox, float &oy, mwc_t &r)
+                                                float &ox, float &oy, mwc_t &r, const XfTail *tl = nullptr)
 {
     if constexpr (J < kSpecNvar[I]) {
-        const float *__restrict__ v = xf + FL_XF_HDR + J * FL_SPEC_VAR_STRIDE;
-        apply_variation_body(kSpecVid[I][J], J == 0 ? w0 : v[1], v + 2, xf, tx, ty, ox, oy, r);
-        spec_variations<I, J + 1>(xf, w0, tx, ty, ox, oy, r);
+        constexpr int B = FL_XF_HDR + J * FL_SPEC_VAR_STRIDE;
+        const VTail v = {xf, tl, B + 2}, vh = {xf, tl, B};
+        apply_variation_body(kSpecVid[I][J], J == 0 ? w0 : vh[1], v, xf, tx, ty, ox, oy, r);
+        spec_variations<I, J + 1>(xf, w0, tx, ty, ox, oy, r, tl);
     }
 }
 
@@ -172,12 +192,12 @@ struct XfVec { float xo, yo, cprod, pxo, pyo; };
 constexpr bool kTab = !kSpecResident && FL_HOIST_BUDGET >= 12 && FL_SPEC_NXF * 16 <= FL_XTAB_BYTES;
 template <int I>
 __device__ __forceinline__ void spec_apply_xf_tab(const XfHead &h, const float4 &t, const float *__restrict__ xf,
-                                                  float &x, float &y, float &c, mwc_t &r)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl)
 {
     float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, t.x));
     float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, t.y));
     float ox = -0.0f, oy = -0.0f;
-    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
+    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r, tl);
     if constexpr (kSpecPost[I] != 0) {
         const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, h.f[8]));
         const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, h.f[11]));
@@ -189,13 +209,13 @@ __device__ __forceinline__ void spec_apply_xf_tab(const XfHead &h, const float4 
 }
 template <int LO, int HI>
 __device__ __forceinline__ void spec_dispatch_tab(int k, const XfHead &h, const float4 &t, const float *__restrict__ xf,
-                                                  float &x, float &y, float &c, mwc_t &r)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl = nullptr)
 {
-    if constexpr (HI - LO == 1) spec_apply_xf_tab<LO>(h, t, xf, x, y, c, r);
+    if constexpr (HI - LO == 1) spec_apply_xf_tab<LO>(h, t, xf, x, y, c, r, tl);
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch_tab<LO, MID>(k, h, t, xf, x, y, c, r);
-        else spec_dispatch_tab<MID, HI>(k, h, t, xf, x, y, c, r);
+        if (k < MID) spec_dispatch_tab<LO, MID>(k, h, t, xf, x, y, c, r, tl);
+        else spec_dispatch_tab<MID, HI>(k, h, t, xf, x, y, c, r, tl);
     }
 }
 // The final xform's record is constant for the slot as well: its operands are held the same way (three registers, five with a post affine).
@@ -454,6 +474,13 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     constexpr bool RESIDENT = false;
 #endif
     XfHead hnext = RESIDENT ? XfHead{} : load_head(xf_next);
+#ifdef FL_RTC
+    XfTail tail_next = {};
+    if constexpr (SPEC && kTab && FL_EARLY_TAIL) {
+#pragma unroll
+        for (int i = 0; i < kTailWords; ++i) tail_next.w[i] = xf_next[kTailFirst + i];
+    }
+#endif
     float4 tcur = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #ifdef FL_RTC
     if constexpr (SPEC && kTab) {
@@ -484,6 +511,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
         const int k_cur = k_next;
         const float *__restrict__ xf_cur = xf_next;
+#ifdef FL_RTC
+        XfTail tail = tail_next;          // (FL_EARLY_TAIL: requested a round ahead, with the head)
+#endif
         sel_next = __builtin_amdgcn_readfirstlane(mwc_next(rctx));
         k_next = choose(sel_next);
         xf_next = P + xf_off + k_next * xf_stride;
@@ -493,12 +523,18 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
         if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx);
-        else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx);
+        else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx, FL_EARLY_TAIL ? &tail : nullptr);
         else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
 #endif
         apply_xf(hnext, xf_cur, var_stride, x, y, color, rctx);
         if constexpr (!RESIDENT) hnext = load_head(xf_next);
+#ifdef FL_RTC
+        if constexpr (SPEC && kTab && FL_EARLY_TAIL) {
+#pragma unroll
+            for (int i = 0; i < kTailWords; ++i) tail_next.w[i] = xf_next[kTailFirst + i];
+        }
+#endif
         (void)k_cur; (void)xf_cur;
 
         // rotate walkers between waves (iter.py:274-294), double-buffered by round parity

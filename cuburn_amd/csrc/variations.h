@@ -103,7 +103,9 @@ __device__ __forceinline__ float v_gauss_r(float w, mwc_t &r) {
 // preheader, where they would run on every round whatever the variation.
 struct VarIO { float tx, ty, ox, oy; uint32_t state, carry; };
 
-__device__ __forceinline__ bool apply_variation_body(int id, float w, const float *__restrict__ v,
+// (V: `const float *` at the variation's parameters, or a view that takes the words a kernel holds in registers from there: iter.hip VTail)
+template <class V>
+__device__ __forceinline__ bool apply_variation_body(int id, float w, const V v,
                                                      const float *__restrict__ xf,
                                                      float &tx, float &ty, float &ox, float &oy, mwc_t &r)
 {
