@@ -222,12 +222,12 @@ __device__ __forceinline__ void spec_dispatch_tab(int k, const XfHead &h, const 
 constexpr bool kHoistFinal = FL_SPEC_FINAL != 0 && FL_HOIST_BUDGET >= 7;
 template <int I, bool COL = kHoistCol, bool AFF = kHoistAff, bool POST = kHoistPost>
 __device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &v, const float *__restrict__ xf,
-                                                  float &x, float &y, float &c, mwc_t &r)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl = nullptr)
 {
     float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, AFF ? v.xo : h.f[2]));
     float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, AFF ? v.yo : h.f[5]));
     float ox = -0.0f, oy = -0.0f;
-    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r);
+    spec_variations<I, 0>(xf, h.w0, tx, ty, ox, oy, r, tl);
     if constexpr (kSpecPost[I] != 0) {
         const float qx = fmaf(h.f[6], ox, fmaf(h.f[7], oy, POST ? v.pxo : h.f[8]));
         const float qy = fmaf(h.f[9], ox, fmaf(h.f[10], oy, POST ? v.pyo : h.f[11]));
@@ -240,13 +240,13 @@ __device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &
 }
 template <int LO, int HI>
 __device__ __forceinline__ void spec_dispatch_res(int k, const XfHead (&heads)[FL_SPEC_NXF], const XfVec (&hv)[FL_SPEC_NXF], const float *__restrict__ xf0, int xf_stride,
-                                                  float &x, float &y, float &c, mwc_t &r)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail (&tails)[FL_SPEC_NXF])
 {
-    if constexpr (HI - LO == 1) spec_apply_xf_res<LO>(heads[LO], hv[LO], xf0 + LO * xf_stride, x, y, c, r);
+    if constexpr (HI - LO == 1) spec_apply_xf_res<LO>(heads[LO], hv[LO], xf0 + LO * xf_stride, x, y, c, r, FL_EARLY_TAIL ? &tails[LO] : nullptr);
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, hv, xf0, xf_stride, x, y, c, r);
-        else spec_dispatch_res<MID, HI>(k, heads, hv, xf0, xf_stride, x, y, c, r);
+        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails);
+        else spec_dispatch_res<MID, HI>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails);
     }
 }
 
@@ -445,10 +445,15 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     constexpr bool RESIDENT = SPEC && kSpecResident;
     XfHead heads[FL_SPEC_NXF];
     XfVec hv[FL_SPEC_NXF] = {};
+    XfTail tails[FL_SPEC_NXF] = {};        // resident kernels: the words behind each head that the record's variations read stay in scalar registers too (the others are dead code)
     if constexpr (RESIDENT) {
 #pragma unroll
         for (int i = 0; i < FL_SPEC_NXF; ++i) {
             heads[i] = load_head(P + xf_off + i * xf_stride);
+            if constexpr (FL_EARLY_TAIL) {
+#pragma unroll
+                for (int k = 0; k < kTailWords; ++k) tails[i].w[k] = (P + xf_off + i * xf_stride)[kTailFirst + k];
+            }
             if constexpr (kHoistCol) {
                 const float csp = heads[i].f[13];
                 hv[i].cprod = heads[i].f[12] * csp;
@@ -460,9 +465,14 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         }
     }
     XfHead hfin_res = {};
+    XfTail tfin = {};                      // (the final xform's record is constant for the slot: its tail words in use stay in registers as well)
     XfVec vfin = {};
     if constexpr (SPEC && kHoistFinal) {
         hfin_res = load_head(xf_final);
+        if constexpr (FL_EARLY_TAIL) {
+#pragma unroll
+            for (int k = 0; k < kTailWords; ++k) tfin.w[k] = xf_final[kTailFirst + k];
+        }
         const float csp = hfin_res.f[13];
         vfin.cprod = hfin_res.f[12] * csp;
         vfin.xo = hfin_res.f[2]; vfin.yo = hfin_res.f[5];
@@ -522,7 +532,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // on this kernel's critical path) and still has the swap, the barrier and the rest of the round to
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
-        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx);
+        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx, tails);
         else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx, FL_EARLY_TAIL ? &tail : nullptr);
         else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
         else
@@ -606,7 +616,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         float fx = x, fy = y, fc = color;
 #ifdef FL_RTC
         if constexpr (SPEC) {
-            if constexpr (kHoistFinal) spec_apply_xf_res<FL_SPEC_NXF, true, true, true>(hfin_res, vfin, xf_final, fx, fy, fc, rctx);
+            if constexpr (kHoistFinal) spec_apply_xf_res<FL_SPEC_NXF, true, true, true>(hfin_res, vfin, xf_final, fx, fy, fc, rctx, FL_EARLY_TAIL ? &tfin : nullptr);
             else if constexpr (FL_SPEC_FINAL != 0) { const XfHead hfin = load_head(xf_final); spec_apply_xf<FL_SPEC_NXF>(hfin, xf_final, fx, fy, fc, rctx); }
         } else
 #endif
