@@ -577,7 +577,9 @@ static int ensure_binned(fl_ctx *c, const fl_dim &d, uint32_t write_rounds, int 
     if (*nbins > FL_MAX_BINS_WIDE) return fail(FL_E_UNSUPPORTED, "image too large for the binned accumulate (> 8191 tiles of 256x64)", __FILE__, __LINE__);
     const uint32_t per_slot = (write_rounds + c->bin_rounds - 1) / c->bin_rounds;
     *nbatch_total = per_slot * c->nslots;
-    size_t lw = (size_t)*nbatch_total * c->bin_rounds * nt * FL_REC_BYTES / 4 + 8, dw = (size_t)*nbins * *nbatch_total;      // records of FL_REC_BYTES bytes (+ slack for the last record's 4-byte load)
+    // 32-bit words of the log: a region per batch — bin_rounds * nt records, one per word (256x64 tiles) or three per 64-bit word (flame_device.h)
+    const size_t region = !*wide && FL_LOG_PACK3 ? 2 * (size_t)fl_pack3_words(c->bin_rounds * nt) : (size_t)c->bin_rounds * nt;
+    size_t lw = (size_t)*nbatch_total * region + 8, dw = (size_t)*nbins * *nbatch_total;
     if (lw > L(c).log_words[buf]) {
         HIPCHK(hipStreamSynchronize(L(c).stream)); HIPCHK(hipStreamSynchronize(L(c).aux));
         hipFree(L(c).d_log[buf]); L(c).d_log[buf] = nullptr; L(c).log_words[buf] = 0;

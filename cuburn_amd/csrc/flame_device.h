@@ -90,9 +90,15 @@ __device__ __forceinline__ uint32_t trunca(float f) {
 #define FL_TILE_H (1u << FL_TILE_H_LOG2)
 #define FL_TILE_CELLS (FL_TILE_W * FL_TILE_H)
 #define FL_REC_BITS (15u + FL_TILE_H_LOG2)   /* ly + lx 7 + ci 8 */
-#ifndef FL_REC_BYTES
-#define FL_REC_BYTES 4    /* bytes of a sample-log record in HBM: 4, or 3 (packed: 21 / 22 payload bits) */
+// The sample log of 128x64 tiles holds THREE 21-bit records per aligned 64-bit word (record i of a sorted batch: bits 21 * (i % 3) ...
+// of word i / 3; bit 63 unused): 2.67 bytes per sample instead of 4.  A tile's run may begin and end inside a word; the words at its
+// ends are then shared with the neighbouring tiles' runs, and every reader takes the slots its directory entry names.
+// 256x64 tiles (22-bit records) keep one record per 32-bit word.  -DFL_LOG_PACK3=0: 32-bit words everywhere (the format of rounds 1-5).
+#ifndef FL_LOG_PACK3
+#define FL_LOG_PACK3 1
 #endif
+// 64-bit words of one batch's region of the packed log (even: the regions are 16-byte aligned)
+__host__ __device__ static inline uint32_t fl_pack3_words(uint32_t batch_records) { return ((batch_records + 2u) / 3u + 1u) & ~1u; }
 #define FL_MAX_BINS 2047u                      /* 128x64 tiles: tile number shares the 32-bit staged record */
 #define FL_TILE_W_WIDE_LOG2 8u                 /* 256x64 tiles for larger images (tile number staged separately) */
 #define FL_MAX_BINS_WIDE 8191u

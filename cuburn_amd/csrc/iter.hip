@@ -299,7 +299,8 @@ struct BinGeom {
     uint32_t nbatch_total;   // batches of this launch = nslots * batches per slot
     uint32_t sub_log2;       // 0: a temporal sample per workgroup; 1 (8 waves) / 2 (16 waves): every four waves walk their own sample (2 or 4 per slot), see iter_body
 };
-// log: [nbatch_total * R * NT] sorted records; dir: [B][nbatch_total] (first record << 16) | count.
+// log: per batch a region of sorted records — R * NT 32-bit words (256x64 tiles), or fl_pack3_words(R * NT) 64-bit words of three
+// records each (128x64 tiles, FL_LOG_PACK3); dir: [B][nbatch_total] (first record << 16) | count.
 // They are separate __restrict__ kernel arguments: as members of the struct the compiler has to
 // assume their stores may alias the parameter block, and every (wave-uniform) parameter load in
 // the loop stops being an s_load.
@@ -333,6 +334,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
     constexpr int NT = NW * 64;
     constexpr int SETS = NW == 4 ? FL_CNT_SETS : FL_CNT_SETS_BIG;
     constexpr bool BINNED = ACC == 1 || ACC == 3, WIDE = ACC == 3;
+    constexpr bool PACK3 = FL_LOG_PACK3 != 0 && ACC == 1;              // 128x64 tiles: three 21-bit records per 64-bit log word
     constexpr uint32_t TWL = WIDE ? FL_TILE_W_WIDE_LOG2 : 7u;          // log2 of the tile width
     constexpr uint32_t PAY_BITS = TWL + FL_TILE_H_LOG2 + 8u;          // row | column | palette column
     // all LDS is carved from the dynamic region (16-byte aligned pieces)
@@ -772,23 +774,27 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 }
                 __syncthreads();
                 const uint32_t nvalid = *s_nvalid;
-                const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-#if FL_REC_BYTES == 3
-                // records are 21 / 22 bits (row | column | palette column): four of them leave as three words —
-                // the log is what the accumulate streams, and it is bound by those bytes
-                {
-                    struct __attribute__((packed, aligned(4))) W3 { uint32_t a, b, c; };
-                    W3 *dst = reinterpret_cast<W3 *>(reinterpret_cast<unsigned char *>(bin_log) + (size_t)batch_id * bg.rounds * NT * 3u);
-                    for (uint32_t i = tid; i * 4 < nvalid; i += NT) {
-                        const uint4 r = src[i];
-                        W3 o;
-                        o.a = r.x | (r.y << 24); o.b = (r.y >> 8) | (r.z << 16); o.c = (r.z >> 16) | (r.w << 8);
-                        dst[i] = o;
-                    }
-                }
-#else
-                uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
+                if constexpr (PACK3) {
+                    // three 21-bit records to an aligned 64-bit word (flame_device.h): the log is what the accumulate streams, and at
+                    // 1080p it is bound by those bytes.  The slots behind the batch's last record hold whatever the LDS held (the
+                    // accumulate takes only the slots its directory entries name; a stale word's high bits land in slots that are
+                    // stale themselves).  12-byte stride per lane: conflict-free.
+                    typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+                    u32x2_ *d2 = reinterpret_cast<u32x2_ *>(bin_log) + (size_t)batch_id * fl_pack3_words(bg.rounds * NT);
+                    const uint32_t nwords = (nvalid + 2u) / 3u;
+                    for (uint32_t i = tid; i < nwords; i += NT) {
+                        const uint32_t a = stage[3u * i], b = stage[3u * i + 1u], c3 = stage[3u * i + 2u];
+                        u32x2_ o;
+                        o.x = a | (b << 21); o.y = (b >> 11) | (c3 << 10);
 #if FL_LOG_NT      /* the log is written once and read by another kernel much later */
+                        __builtin_nontemporal_store(o, d2 + i);
+#else
+                        d2[i] = o;
+#endif
+                    }
+                } else {
+                uint4 *dst = reinterpret_cast<uint4 *>(bin_log + (size_t)batch_id * bg.rounds * NT);
+#if FL_LOG_NT
                 {
                     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
                     const u32x4_ *s4 = reinterpret_cast<const u32x4_ *>(stage);
@@ -796,9 +802,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                     for (uint32_t i = tid; i * 4 < nvalid; i += NT) __builtin_nontemporal_store(s4[i], d4 + i);
                 }
 #else
-                for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = src[i];
+                for (uint32_t i = tid; i * 4 < nvalid; i += NT) dst[i] = reinterpret_cast<const uint4 *>(stage)[i];
 #endif
-#endif
+                }
                 for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
                 ++batch_in_slot;
                 __syncthreads();

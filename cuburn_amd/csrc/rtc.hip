@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 #include "kernels.h"
+#include "flame_device.h"      // the compile-time switches the run-time build must share with this library (FL_LOG_PACK3)
 #define FL_STR2(x) #x
 #define FL_STR(x) FL_STR2(x)
 #include "rtc_sources.inc"
@@ -127,7 +128,7 @@ int rtc_compile(const IterSpec &spec, int nw, bool count, int acc, std::vector<c
 #ifdef FL_CNT_SETS_BIG
                           "-DFL_CNT_SETS_BIG=" FL_STR(FL_CNT_SETS_BIG),
 #endif
-                          "-DFL_REC_BYTES=" FL_STR(FL_REC_BYTES),
+                          "-DFL_LOG_PACK3=" FL_STR(FL_LOG_PACK3),
 #ifdef FL_BIN_R_MAX
                           "-DFL_BIN_R_MAX=" FL_STR(FL_BIN_R_MAX),
 #endif

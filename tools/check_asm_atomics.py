@@ -5,8 +5,8 @@ nothing may touch a result register between its instruction and the wait.  This 
 (hipcc --cuda-device-only -S binned.hip, with the flags of the build) and checks exactly that.  The walk follows
 program text order (forward branches are not followed: everything in the text counts as executed, which is the
 feasible path of the pipelined loop from its second iteration on) and starts afresh after every unconditional
-branch (blocks placed out of line are entered from elsewhere); at every BACKWARD conditional branch — a loop's
-back-edge — the loop body is walked a second time with the state the first pass ended with, so that what stays in
+branch (blocks placed out of line are entered from elsewhere); at every BACKWARD branch — a loop's
+back-edge, conditional or not — the loop body is walked a second time with the state the first pass ended with, so that what stays in
 flight ACROSS iterations (the pipelined loop's second record set) meets the top of the loop again.
 (A walk of every path of the control-flow graph was tried: it reports the infeasible path that skips the
 `v0 != 0` wait in a later iteration.)
@@ -17,6 +17,7 @@ import sys
 lines = open(sys.argv[1]).read().split('\n')
 ATOM = re.compile(r'global_atomic_add_x2 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off sc0')
 LOAD = re.compile(r'global_load_dword v(\d+), v(\d+), s\[(\d+):(\d+)\]$')          # the record loads of the pipelined loop (asm: no offset field)
+LOAD2 = re.compile(r'global_load_dwordx2 v\[(\d+):(\d+)\], v(\d+), s\[(\d+):(\d+)\]$')      # ... of the packed log: three records per 64-bit word
 WAITN = re.compile(r's_waitcnt .*vmcnt\(([1-9]\d*)\)|s_waitcnt vmcnt\(([1-9]\d*)\)')
 LABEL = re.compile(r'^(\.LBB\d+_\d+):')
 FUNC = re.compile(r'^(_Z\w+):')
@@ -36,15 +37,16 @@ def parse(t):
     mw = WAITN.match(t)
     if mw:
         return ('waitn', int(mw.group(1) or mw.group(2)), None, t, None)
-    ma, ml = ATOM.match(t), LOAD.match(t)
-    if ma or ml:
-        d = tuple(range(int(ma.group(1)), int(ma.group(2)) + 1)) if ma else (int(ml.group(1)),)
+    ma, ml, ml2 = ATOM.match(t), LOAD.match(t), LOAD2.match(t)
+    if ma or ml or ml2:
+        mr = ma or ml2
+        d = tuple(range(int(mr.group(1)), int(mr.group(2)) + 1)) if mr else (int(ml.group(1)),)
         return ('atom' if ma else 'load', frozenset(regs_of(t)), d, t, None)
     m = LABEL.match(t)
     if m:
         return ('label', None, None, t, m.group(1))
     if t.startswith('s_branch') or t.startswith('s_endpgm') or t.startswith('s_setpc'):
-        return ('reset', None, None, t, None)
+        return ('reset', None, None, t, t.split()[1] if t.startswith('s_branch') else None)
     if t.startswith('s_cbranch'):
         return ('cjump', None, None, t, t.split()[1])
     return ('op', frozenset(regs_of(t)), None, t, None)
@@ -66,6 +68,9 @@ def check_function(name, body):
             elif kind == 'waitn':
                 loads = loads[-regs:]                   # the newest n loads stay in flight
             elif kind == 'reset':
+                # an unconditional branch BACK is a back-edge too (rotated loops end in one): once more over the body
+                if not second and target in where and where[target] < k and (atoms or loads):
+                    walk(where[target], k, atoms, loads, True)
                 atoms, loads = set(), []
             elif kind in ('atom', 'load'):
                 inflight = {r for a in atoms for r in a} | {r for l in loads for r in l}
