@@ -22,7 +22,6 @@
 #include "flame_device.h"
 #include "kernels.h"
 #include <cstdlib>
-#include <type_traits>
 
 __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restrict__ out4)
 {
@@ -95,9 +94,6 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #endif
 #ifndef ACC_DIR_AHEAD
 #define ACC_DIR_AHEAD 1        /* a group's directory words are requested one group ahead (the first group's before the tile is zeroed) */
-#endif
-#ifndef ACC_ILP_P3
-#define ACC_ILP_P3 2       /* 64-bit log words (three records each) per lane and step, 128x64 tiles with the packed log */
 #endif
 #ifndef ACC_LOAD_MOD
 #define ACC_LOAD_MOD ""        /* cache policy of the record loads (" nt", " sc1", ...): experiment, see profiles/r03_accum_cache_policy.txt */
@@ -188,13 +184,12 @@ __device__ __forceinline__ void add_tile_to_cells(const u64 *tile, u64 *__restri
 
 // TWL: log2 of the tile width (7: 128x64 tiles = 64 KB of LDS cells, two workgroups per CU;
 // 8: 256x64 tiles = 128 KB, for images with more than 2047 narrow tiles)
-// P3: the log holds three 21-bit records per 64-bit word (128x64 tiles, FL_LOG_PACK3); `batch_stride` is then a batch's region in
-// 64-bit words, otherwise in records (32-bit words)
+// One record per 32-bit log word: 256x64 tiles, and 128x64 tiles of a build without FL_LOG_PACK3 (the packed log has its own kernel below).
 // 80 SGPRs including VCC etc.: two 16-wave workgroups per CU need 8 waves per SIMD, and a CU of this GPU holds
 // 8 waves per SIMD only up to 80 SGPRs per wave (measured: tools/occupancy_probe.hip,
 // profiles/r03_occupancy_probe.txt; the compiler's table and the occupancy API say 96)
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-template <uint32_t TWL, bool P3>
+template <uint32_t TWL>
 __global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024, TWL == 7u ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
@@ -203,11 +198,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
-    constexpr int ILP = P3 ? ACC_ILP_P3 : TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;      // log words per lane and step
-    constexpr int NREC = P3 ? 3 : 1;                                                 // records per log word
-    static_assert(!P3 || TWL == 7u, "three records per word are 21-bit records");
+    constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;                           // records per lane and step
     static_assert(FL_PAL_W == 256, "the palette column is the record's low byte, the row the mark's");
-    using Word = typename std::conditional<P3, u32x2_t, uint32_t>::type;
+    using Word = uint32_t;
     // LDS: palette rows first (their gather then needs no base added), the waves' marks, the tile
     u64 *pal = reinterpret_cast<u64 *>(smem);                                                   // [rows_cap][256] palette rows in use
     uint32_t *mk = reinterpret_cast<uint32_t *>(smem + rows_cap * FL_PAL_W * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
@@ -297,12 +290,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #else
         const uint32_t e = batch < ce ? drow[batch] : 0u;
 #endif
-        // the run of this lane's batch: `first` = the log word its first record lies in (counted inside the batch's region), `c` = the
-        // words it touches.  Packed log: records first .. first + count - 1 lie in words first / 3 .. (first + count - 1) / 3; the words at
-        // the run's ends may hold the neighbouring tiles' records as well.
-        const uint32_t cnt_l = e & 0xffffu, rfirst = e >> 16;
-        const uint32_t first = P3 ? rfirst / 3u : rfirst;
-        const uint32_t c = !P3 ? cnt_l : cnt_l ? (rfirst + cnt_l - 1u) / 3u - first + 1u : 0u;
+        const uint32_t c = e & 0xffffu, first = e >> 16;                  // the run of this lane's batch: its records, its first record
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
         const uint32_t total = __shfl(incl, 63);
@@ -333,7 +321,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
             // of one are filled by the others), and the marks themselves come from the runs' lanes by ds_bpermute —
             // two waits on the LDS pipe per step instead of ILP.  (carry: the run number + 1)
             unsigned char *mk8 = reinterpret_cast<unsigned char *>(mk);
-            const bool starts = (P3 ? (e & 0xffffu) : c) != 0u && excl - v0 < 64u * ILP;      // (packed log: e stays live for the slots anyway, c need not)
+            const bool starts = c != 0u && excl - v0 < 64u * ILP;
             if (starts) mk8[excl - v0] = (unsigned char)(lane + 1u);
             wave_sync();
             uint32_t mm[ILP];
@@ -353,51 +341,24 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                 const uint32_t v = v0 + k * 64 + lane;
                 const uint32_t run = mm[k] - 1u;                   // the directory lane of the word's run
                 const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(run << 2), (int)mark_l);
-                uint32_t meta = m;                                 // its low byte goes into byte k of `rows`
-                if constexpr (P3) {
-                    // Slot j of the word is record 3 * (word within the batch) + j of the sorted batch; it belongs to the run iff that
-                    // index lies in [first record, first record + count): with nq = first record - 3 * word, slots [lo, hi) =
-                    // [clamp(nq), clamp(nq + count)) of 0..3, as three bits above the row (positions past the end: count 0, no slot).
-                    const uint32_t er = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(run << 2), (int)e);
-                    const uint32_t wb = (m >> 8) - 1u + v - run * batch_stride;
-                    const int nq = (int)(er >> 16) - (int)(3u * wb);
-                    const int cr = v < total ? (int)(er & 0xffffu) : 0;
-                    const int lo = min(max(nq, 0), 3), hi = min(max(nq + cr, 0), 3);
-                    const uint32_t live3 = (7u << lo) & (7u >> (3 - hi));
-                    meta = (m & 15u) | (live3 << 4);
-                }
-                rows = __builtin_amdgcn_perm(meta, rows, k == 0 ? 0x03020104u : k == 1 ? 0x03020400u : k == 2 ? 0x03040100u : 0x04020100u);
+                rows = __builtin_amdgcn_perm(m, rows, k == 0 ? 0x03020104u : k == 1 ? 0x03020400u : k == 2 ? 0x03040100u : 0x04020100u);
                 // scalar base + 32-bit byte offset (at most 65 batch regions); positions past the end of the
                 // virtual array read the group's first word (and are not used)
                 const uint32_t voff = v < total ? ((m >> 8) + v) * (uint32_t)sizeof(Word) : (uint32_t)sizeof(Word);
-                if constexpr (P3) asm volatile("global_load_dwordx2 %0, %1, %2" ACC_LOAD_MOD : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
-                else asm volatile("global_load_dword %0, %1, %2" ACC_LOAD_MOD : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
+                asm volatile("global_load_dword %0, %1, %2" ACC_LOAD_MOD : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
             }
         };
         auto process = [&](const uint32_t v0, Word (&rec)[ILP], const uint32_t rows) __attribute__((always_inline)) {
-            // the step's words in groups of GW: every word on its own with the packed log (three records; more in flight do not fit
-            // the 64 registers), all ILP one-record words together otherwise
-            constexpr int GW = P3 ? 1 : ILP, NR = GW * NREC;
-#pragma unroll
-            for (int k0 = 0; k0 < ILP; k0 += GW) {
+            constexpr int NR = ILP;
+            constexpr int k0 = 0;
+            {
             bool live[NR];
             uint32_t r[NR];                                        // {row in tile | column | palette column}
             u64 val[NR];
-            if constexpr (P3) {
-                const uint32_t wl = rec[k0].x, wh = rec[k0].y;
-                r[0] = wl & 0x1fffffu;
-                r[1] = __builtin_amdgcn_alignbit(wh, wl, 21) & 0x1fffffu;
-                r[2] = __builtin_amdgcn_ubfe(wh, 10, 21);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) live[j] = (rows >> (8 * k0 + 4 + j) & 1u) != 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < ILP; ++k) { r[k] = rec[k]; live[k] = v0 + k * 64 + lane < total; }
-            }
+            for (int k = 0; k < ILP; ++k) { r[k] = rec[k]; live[k] = v0 + k * 64 + lane < total; }
             auto gather = [&](const int i) __attribute__((always_inline)) {
-                // (row << 8) | colour byte: FL_PAL_W == 256.  (Packed log: the row's byte carries the slot bits above bit 3; rows_cap <= 12)
-                const uint32_t rowb = P3 ? rows & 0x0f0f0f0fu : rows;
-                val[i] = pal[__builtin_amdgcn_perm(rowb, r[i], 0x0c0c0000u | ((4u + k0 + i / NREC) << 8))];
+                val[i] = pal[__builtin_amdgcn_perm(rows, r[i], 0x0c0c0000u | ((4u + k0 + i) << 8))];      // (row << 8) | colour byte: FL_PAL_W == 256
             };
 #pragma unroll
             for (int i = 0; i < NR; ++i)
@@ -469,7 +430,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #endif
         for (uint32_t v0 = 0; v0 < total; v0 += 2 * STEP) {
             ACC_T(x_other); fetch(v0, recA, rowsA); ACC_T(x_fetch);
-            if (v0 != 0u) { ACC_WAIT_NEWER(recB); ACC_T(x_wait); process(v0 - STEP, recB, rowsB); ACC_T(x_proc); }       // B is older than A: A stays in flight
+            // B is older than A: A stays in flight.  (The wait is executed in the first iteration too, where it is satisfied at once: no path
+            // reaches B's next request with a load of B in flight.)
+            ACC_WAIT_NEWER(recB); if (v0 != 0u) { ACC_T(x_wait); process(v0 - STEP, recB, rowsB); ACC_T(x_proc); }
             if (v0 + STEP < total) { fetch(v0 + STEP, recB, rowsB); ACC_T(x_fetch); ACC_WAIT_NEWER(recA); } else ACC_WAIT(0, recA);
             ACC_T(x_wait); process(v0, recA, rowsA); ACC_T(x_proc);
 #ifdef ACC_X_TIMES
@@ -695,12 +658,14 @@ k_accum_tiles_p3(const uint32_t *__restrict__ log, const uint32_t *__restrict__ 
         const uint32_t nsteps = (total + 63u) >> 6;
 #define P3_WAIT(w) asm volatile("s_waitcnt vmcnt(2)" : "+v"(w) :: "memory")
         for (uint32_t s = 0; s < nsteps + 2u; s += 3u) {              // (no early exits: a fetch behind the last step is a branch and one load)
+            // (every wait is executed, whether or not its set is then added — at the ends of the array it is satisfied at once —, so that no
+            // path reaches a set's next request with an earlier load of the set still in flight: its registers are the lookup's scratch)
             fetch(s << 6, wA, mA);
-            if (s >= 2u && s - 2u < nsteps) { P3_WAIT(wB); process(wB, mB); }
+            P3_WAIT(wB); if (s >= 2u && s - 2u < nsteps) process(wB, mB);
             fetch((s + 1u) << 6, wB, mB);
-            if (s >= 1u && s - 1u < nsteps) { P3_WAIT(wC); process(wC, mC); }
+            P3_WAIT(wC); if (s >= 1u && s - 1u < nsteps) process(wC, mC);
             fetch((s + 2u) << 6, wC, mC);
-            if (s < nsteps) { P3_WAIT(wA); process(wA, mA); }
+            P3_WAIT(wA); if (s < nsteps) process(wA, mA);
         }
         // (the loads behind the last step: nothing may be in flight into a set when the next group's first fetch uses the
         // set's registers — to the compiler they are free until the load defines them)
@@ -740,27 +705,24 @@ void launch_accum_tiles(hipStream_t st, const uint32_t *log, const uint32_t *dir
     if (wide) {
         const uint32_t rows = want < 2u ? 2u : want > 12u ? 12u : want;
         static unsigned long long attr = 0;
-        ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2, false>, attr);
-        hipLaunchKernelGGL((k_accum_tiles<FL_TILE_W_WIDE_LOG2, false>), dim3(grid), dim3(1024),
+        ensure_max_dynamic_lds((const void *)k_accum_tiles<FL_TILE_W_WIDE_LOG2>, attr);
+        hipLaunchKernelGGL((k_accum_tiles<FL_TILE_W_WIDE_LOG2>), dim3(grid), dim3(1024),
                            (FL_TILE_H << FL_TILE_W_WIDE_LOG2) * 8 + 1024 * 4 + rows * FL_PAL_W * 8, st,
                            log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr, gang, nbins);
         return;
     }
     const uint32_t rows = want < 2u ? 2u : want > (uint32_t)ACC_ROWS_MAX ? (uint32_t)ACC_ROWS_MAX : want;
     static unsigned long long attr = 0;
-    // 128x64 tiles: three records per 64-bit log word, a batch's region in such words (flame_device.h)
-    constexpr bool P3 = FL_LOG_PACK3 != 0;
-    const uint32_t stride = P3 ? fl_pack3_words(batch_records) : batch_records;
-#if FL_LOG_PACK3 && !defined(ACC_P3_TEMPLATE)
-    {
+#if FL_LOG_PACK3
+    {   // 128x64 tiles: three records per 64-bit log word, a batch's region in such words (flame_device.h)
         static unsigned long long attr3 = 0;
         ensure_max_dynamic_lds((const void *)k_accum_tiles_p3, attr3);
         hipLaunchKernelGGL(k_accum_tiles_p3, dim3(grid), dim3(ACC_THREADS), P3_LDS, st,
-                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, stride, nslots, astride, aheight, rows, big_thr, gang, nbins);
+                           log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, fl_pack3_words(batch_records), nslots, astride, aheight, rows, big_thr, gang, nbins);
         return;
     }
 #endif
-    ensure_max_dynamic_lds((const void *)k_accum_tiles<7u, P3>, attr);
-    hipLaunchKernelGGL((k_accum_tiles<7u, P3>), dim3(grid), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
-                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, stride, nslots, astride, aheight, rows, big_thr, gang, nbins);
+    ensure_max_dynamic_lds((const void *)k_accum_tiles<7u>, attr);
+    hipLaunchKernelGGL((k_accum_tiles<7u>), dim3(grid), dim3(ACC_THREADS), FL_TILE_CELLS * 8 + ACC_THREADS * 4 + rows * FL_PAL_W * 8, st,
+                       log, dir, palette, atom, out4, tiles_x, nparts, nbatch_total, batch_records, nslots, astride, aheight, rows, big_thr, gang, nbins);
 }

@@ -283,10 +283,33 @@ def test_asm_issued_loads_are_not_touched_in_flight(tmp_path):
         out = subprocess.run([sys.executable, checker, inj], capture_output=True, text=True, timeout=120)
         flagged += out.returncode != 0 and 'second pass' in out.stdout
     assert 2 <= flagged <= 4, flagged                      # one of the two record sets (2-4 registers) is in flight there
-    # resource usage of the narrow kernel, from the compiler's remarks
-    rem = r.stderr[r.stderr.index('k_accum_tilesILj7'):]
-    num = lambda key: int(re.search(key + r': (\d+)', rem).group(1))
-    assert num('VGPRs') <= 64 and num('TotalSGPRs') <= 80 and num(r'ScratchSize \[bytes/lane\]') == 0, rem[:1200]
+    # resource usage of the two 128x64-tile kernels (the packed log's, and the 32-bit log's of a build without it), from the compiler's remarks
+    for kern in ('k_accum_tiles_p3', 'k_accum_tilesILj7'):
+        rem = r.stderr[r.stderr.index(kern):]
+        num = lambda key: int(re.search(key + r': (\d+)', rem).group(1))
+        assert num('VGPRs') <= 64 and num('TotalSGPRs') <= 80 and num(r'ScratchSize \[bytes/lane\]') == 0, (kern, rem[:1200])
+    # the same self-test on the packed log's loop: three register sets of a 64-bit word each, two of them in flight across the back-edge
+    load2 = re.compile(r'\s*global_load_dwordx2 v\[(\d+):(\d+)\], v(\d+), s\[(\d+):(\d+)\]$')
+    p3 = [i for i, l in enumerate(lines) if 'k_accum_tiles_p3' in l and l.rstrip().endswith(':') or l.startswith('_Z16k_accum_tiles_p3')]
+    lo = min(i for i, l in enumerate(lines) if l.startswith('_Z16k_accum_tiles_p3'))
+    hi = min(i for i, l in enumerate(lines) if i > lo and l.startswith('_Z13k_accum_tiles'))
+    loads2 = [(i, int(load2.match(l).group(1)), int(load2.match(l).group(2))) for i, l in enumerate(lines) if lo < i < hi and load2.match(l)]
+    assert len(loads2) == 3, loads2                          # one request site per set
+    head = back = None
+    for i in range(loads2[-1][0], hi):
+        t = lines[i].strip().split()
+        if t and t[0].startswith('s_cbranch') and t[1] in labels and labels[t[1]] < loads2[0][0]:
+            head, back = labels[t[1]], i
+            break
+    assert head is not None
+    flagged = 0
+    for _, a, b in loads2:
+        for reg in range(a, b + 1):
+            inj = str(tmp_path / 'inj2.s')
+            open(inj, 'w').write('\n'.join(lines[:head + 1] + ['\tv_mov_b32_e32 v0, v%d' % reg] + lines[head + 1:]))
+            out = subprocess.run([sys.executable, checker, inj], capture_output=True, text=True, timeout=120)
+            flagged += out.returncode != 0 and 'second pass' in out.stdout
+    assert flagged == 4, flagged                             # two of the three sets are in flight at the top of the loop
 
 
 def test_de_kernels_hold_32_waves_per_cu_without_scratch(tmp_path):

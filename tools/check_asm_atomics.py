@@ -3,8 +3,9 @@
 them itself (all of them, or all but the newest loads); the compiler does not know the results are in flight, so
 nothing may touch a result register between its instruction and the wait.  This reads the device assembly
 (hipcc --cuda-device-only -S binned.hip, with the flags of the build) and checks exactly that.  The walk follows
-program text order (forward branches are not followed: everything in the text counts as executed, which is the
-feasible path of the pipelined loop from its second iteration on) and starts afresh after every unconditional
+program text order (everything in the text counts as executed, which is the feasible path of the pipelined loop from its
+second iteration on; a FORWARD branch carries its state to its label, where the state with more in flight continues —
+the main path jumps over blocks the compiler placed out of line) and starts afresh after every unconditional
 branch (blocks placed out of line are entered from elsewhere); at every BACKWARD branch — a loop's
 back-edge, conditional or not — the loop body is walked a second time with the state the first pass ended with, so that what stays in
 flight ACROSS iterations (the pipelined loop's second record set) meets the top of the loop again.
@@ -61,8 +62,21 @@ def check_function(name, body):
     def walk(lo, hi, atoms, loads, second):
         """Text-order walk of ins[lo:hi]; returns the state at the end."""
         atoms, loads = set(atoms), list(loads)
+        carried = {}            # label -> state a FORWARD branch brought along (the main path jumps over blocks placed out of line)
+        fresh = False           # the state was dropped at an unconditional branch and nothing has happened since
         for k in range(lo, hi):
             kind, regs, dst, t, target = ins[k]
+            if kind == 'label':
+                c = carried.pop(target, None)
+                if c is not None and (fresh or len(c[0]) + len(c[1]) > len(atoms) + len(loads)):
+                    atoms, loads = set(c[0]), list(c[1])      # (the state with more in flight: the stricter one)
+                fresh = False
+                continue
+            if kind in ('reset', 'cjump') and target in where and where[target] > k:
+                c = carried.get(target)
+                if c is None or len(c[0]) + len(c[1]) < len(atoms) + len(loads):
+                    carried[target] = (set(atoms), list(loads))
+            fresh = fresh and kind not in ('atom', 'load')
             if kind == 'wait0':
                 atoms, loads = set(), []
             elif kind == 'waitn':
@@ -72,6 +86,7 @@ def check_function(name, body):
                 if not second and target in where and where[target] < k and (atoms or loads):
                     walk(where[target], k, atoms, loads, True)
                 atoms, loads = set(), []
+                fresh = True
             elif kind in ('atom', 'load'):
                 inflight = {r for a in atoms for r in a} | {r for l in loads for r in l}
                 hit = ((regs - set(dst)) & inflight) | (set(dst) & inflight)
