@@ -56,6 +56,7 @@ _SIGS = {
     'fl_buffer_ptr': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     'fl_buffer_ptr_async': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     'fl_stream_dependency': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    'fl_reserve': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     'fl_debug_iter_launch': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_int]),
     'fl_debug_flush': (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

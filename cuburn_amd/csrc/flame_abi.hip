@@ -702,7 +702,29 @@ int fl_iterate(fl_ctx *c, fl_genome *g, uint32_t w, uint32_t h, double nsamples,
     // for the same samples per launch, i.e. the same log, flush schedule and number of launches)
     const uint64_t unit = 256ull << c->sub_log2;
     auto launches_with = [rounds, unit](uint64_t cap_) { uint32_t nl = 0; for (uint64_t r = rounds, b = 4; r; b += b / 2) { r -= std::min(std::min(r, b * unit), cap_); ++nl; } return nl; };
-    const uint64_t cap_short = (uint64_t)FL_BIN_MAX_ROUNDS << c->sub_log2, cap_long = (uint64_t)FL_BIN_MAX_ROUNDS_LONG << c->sub_log2;
+    // (16-wave workgroups: the long cap stops at the 1536 rounds that tests/test_gpu_parity.py::test_long_launch_log_beyond_4gb... pins —
+    // a 2304-round launch of the 8K geometry is a 14.5 GB log whose record indices pass 2^31)
+    const uint64_t cap_short = (uint64_t)FL_BIN_MAX_ROUNDS << c->sub_log2;
+    uint64_t cap_long = (uint64_t)(c->nw == 16 ? 1536u : FL_BIN_MAX_ROUNDS_LONG) << c->sub_log2;
+    // The long cap saves a launch but sizes the (grow-only) sample log and directory for the longest launch: it is taken only if what
+    // would have to be allocated beyond the short cap's buffers fits the device's free memory with a margin — a frame that rendered
+    // with 1024-round logs must not start failing on a shared or smaller device because a schedule saves it a flush.
+    if (accum_mode == FL_ACCUM_BINNED && !c->launch_rounds && launches_with(cap_long) < launches_with(cap_short)) {
+        const uint32_t nt_ = (uint32_t)c->nw * 64;
+        const bool wide_ = ((d.astride + 127) / 128) * ((d.ah + FL_TILE_H - 1) / FL_TILE_H) > FL_MAX_BINS || c->env_bin_wide;
+        const uint32_t tw_ = wide_ ? (1u << FL_TILE_W_WIDE_LOG2) : 128u;
+        const size_t nbins_ = (size_t)((d.astride + tw_ - 1) / tw_) * ((d.ah + FL_TILE_H - 1) / FL_TILE_H);
+        const size_t region = !wide_ && FL_LOG_PACK3 ? 2 * (size_t)fl_pack3_words(c->bin_rounds * nt_) : (size_t)c->bin_rounds * nt_;
+        const size_t nb_long = (size_t)((std::min(rounds, cap_long) + c->bin_rounds - 1) / c->bin_rounds) * c->nslots;
+        const size_t need = (nb_long * region + 8 + nbins_ * nb_long) * 4;      // one log + directory set, bytes
+        size_t have = 0, grow = 0;
+        for (int b = 0; b < 2; ++b) {                                            // (two sets: launches of a frame are pipelined)
+            have = (L(c).log_words[b] + L(c).dir_words[b]) * 4;
+            if (need > have) grow += need - have;
+        }
+        size_t mfree = 0, mtotal = 0;
+        if (grow && (hipMemGetInfo(&mfree, &mtotal) != hipSuccess || grow + (size_t(1) << 30) > mfree)) cap_long = cap_short;
+    }
     const uint64_t cap = accum_mode != FL_ACCUM_BINNED ? ~0ull : c->launch_rounds ? c->launch_rounds :
                          launches_with(cap_long) < launches_with(cap_short) ? cap_long : cap_short;
     const uint32_t nlaunch = launches_with(cap);
@@ -1046,6 +1068,14 @@ int fl_buffer_ptr_async(fl_ctx *c, fl_genome *g, int which, void **dev_ptr, size
     HIPCHK(hipSetDevice(c->device));
     flush_pending(c);
     return buf_ptr(c, g, which, dev_ptr, nbytes);
+}
+
+int fl_reserve(fl_ctx *c, uint32_t w, uint32_t h)
+{
+    REQUIRE(c && w && h, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    fl_dim d; fl_calc_dim(w, h, &d);
+    return ensure_fb(c, d);
 }
 
 int fl_stream_dependency(fl_ctx *c, void *stream, int ctx_waits)

@@ -109,6 +109,7 @@ class FrameGather(object):
         self.recv = [[torch.empty_like(b) for _ in range(self.world)] if (self.world > 1 and self.rank == dst) else None
                      for b in self.blocks]
         self.work = [None, None]             # (handle, first frame index, count) per block
+        self.done_ev = [None, None]          # device blocks: an event behind the block's gather on torch's stream
         self.n_alloc = self.n_done = 0
 
     def _harvest(self, b):
@@ -118,10 +119,16 @@ class FrameGather(object):
         if handle is not None:
             handle.wait()
             if self.blocks[b].is_cuda:
-                # Work.wait() on RCCL only makes torch's current stream wait; the frames are written
-                # by the render context's own streams, so the host has to know the gather is over
-                # before the block is handed out again (this is eight frames later: no stall)
-                torch.cuda.current_stream(self.blocks[b].device).synchronize()
+                # Work.wait() on RCCL only makes torch's current stream wait; the frames are written by the render
+                # context's own streams, which must not re-use the block before the gather has read it.  The host polls
+                # an event recorded behind the gather on torch's stream: when the block comes round again — two blocks of
+                # frames later — it has long completed, and the loop does not block (the reference's loop never blocks
+                # inside a frame either, distribute.py:107-122); only a gather that is really still running is waited for.
+                if self.done_ev[b] is None:
+                    self.done_ev[b] = torch.cuda.Event()
+                self.done_ev[b].record(torch.cuda.current_stream(self.blocks[b].device))
+                if not self.done_ev[b].query():
+                    self.done_ev[b].synchronize()
         if self.sink is not None and self.rank == self.dst:
             srcs = self.recv[b] if self.world > 1 else [self.blocks[b]]
             for r, t in enumerate(srcs):
@@ -340,38 +347,74 @@ def halo_plan(plan, rank, ah, halo=BAND_HALO):
     return dict(top=top, bot=bot, sends=sends, recvs=recvs)
 
 
-def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO):
+class ShardBuffers(object):
+    """
+    The device tensors a sample-sharded frame needs besides the accumulator — the band with its halos, the 8-bit band, the
+    gathered frame — allocated once per (frame geometry, world, rank) and re-used by every frame: all of a frame's torch
+    operations are queued on ONE stream in frame order, and the native lanes are ordered against that stream by events
+    (order_streams), so a frame's tensors are free again by the time the next frame's operations on the same stream reach
+    them.  The reference's loop allocates nothing per frame (distribute.py:107-122, cuburn/render.py:107-113).
+    """
+    _cache = {}
+
+    @classmethod
+    def clear(cls):
+        cls._cache.clear()
+
+    @classmethod
+    def get(cls, device, key, make):
+        k = (str(device),) + tuple(key)
+        if k not in cls._cache:
+            if len(cls._cache) > 16:
+                cls._cache.clear()
+            cls._cache[k] = make()
+        return cls._cache[k]
+
+
+def exchange_bands(acc2d, plan, rank, world, halo=BAND_HALO, padded=None):
     """
     ``acc2d``: this rank's accumulator as a (ah, row_floats) tensor.  Sums it over the ranks by bands and
     returns ``(band, top)``: the summed rows ``[r0 - top, r1 + bottom)`` of this rank's band with its
-    halos (``top`` / ``bottom`` = halo, or 0 at the image's own edges), as a new tensor.
+    halos (``top`` / ``bottom`` = halo, or 0 at the image's own edges) — a persistent tensor per geometry
+    (ShardBuffers), valid until the next call with the same geometry on this stream.
     Collective: every rank calls it.  One reduce-scatter (gloo, the CPU tests' backend, has none: all-reduce and
     keep the own band) followed by the neighbour exchange of ``halo_plan`` — the same isend / irecv code on
-    both backends.
+    both backends.  ``padded``: the accumulator with ``rows_per * world`` rows where it lies (the rows behind
+    ``ah`` hold anything: their sums land behind the last band's own rows and are dropped; see fl_reserve) — without
+    it an accumulator whose rows the ranks do not divide is copied into a persistent zero-padded tensor.
     """
     rows_per, bands = plan
     ah, rowf = acc2d.shape
     r0, r1 = bands[rank]
+    hp = halo_plan(plan, rank, ah, halo)
+    top, bot = hp['top'], hp['bot']
+    key = ('band', ah, rowf, world, rank, halo, acc2d.dtype)
+    # one tensor for [top halo | core (a whole band: the reduce-scatter's output) | room for the bottom halo]
+    buf = ShardBuffers.get(acc2d.device, key, lambda: torch.empty((top + rows_per + bot, rowf), dtype=acc2d.dtype, device=acc2d.device))
+    core = buf[top:top + rows_per]
+    n = r1 - r0
     if dist.get_backend() == 'nccl':
-        padded = acc2d
+        src = acc2d
         if rows_per * world != ah:                       # reduce-scatter wants equal chunks
-            padded = torch.zeros((rows_per * world, rowf), dtype=acc2d.dtype, device=acc2d.device)
-            padded[:ah] = acc2d
-        core = torch.empty((rows_per, rowf), dtype=acc2d.dtype, device=acc2d.device)
-        dist.reduce_scatter_tensor(core, padded, op=dist.ReduceOp.SUM)
-        core = core[:r1 - r0]
+            if padded is not None:
+                assert tuple(padded.shape) == (rows_per * world, rowf)
+                src = padded
+            else:
+                src = ShardBuffers.get(acc2d.device, ('pad', ah, rowf, world, acc2d.dtype),
+                                       lambda: torch.zeros((rows_per * world, rowf), dtype=acc2d.dtype, device=acc2d.device))
+                src[:ah].copy_(acc2d)
+        dist.reduce_scatter_tensor(core, src, op=dist.ReduceOp.SUM)
     else:
         dist.all_reduce(acc2d, op=dist.ReduceOp.SUM)
-        core = acc2d[r0:r1]
-    hp = halo_plan(plan, rank, ah, halo)
-    bufs = dict(top=torch.empty((hp['top'], rowf), dtype=acc2d.dtype, device=acc2d.device),
-                bot=torch.empty((hp['bot'], rowf), dtype=acc2d.dtype, device=acc2d.device))
-    ops = [dist.P2POp(dist.isend, core[first:first + rows].contiguous(), peer) for peer, first, rows in hp['sends']]
-    ops += [dist.P2POp(dist.irecv, bufs[side], peer) for peer, side, rows in hp['recvs']]
+        core[:n].copy_(acc2d[r0:r1])
+    # the bottom halo lands directly behind the band's own rows (the last band is short and has none)
+    sides = dict(top=buf[:top], bot=buf[top + n:top + n + bot])
+    ops = [dist.P2POp(dist.isend, core[first:first + rows], peer) for peer, first, rows in hp['sends']]
+    ops += [dist.P2POp(dist.irecv, sides[side], peer) for peer, side, rows in hp['recvs']]
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return torch.cat([bufs['top'], core, bufs['bot']]), hp['top']
+    return buf[:top + n + bot], top
 
 
 def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
@@ -400,7 +443,8 @@ def filter_band(mgr, rdr, gprof, dim, band, tc, device, convert=True):
         filt._run(mgr.fb, bdim, filt.scalars(gprof, params, dim, tc))
     if not convert:
         return None, bdim
-    out = torch.empty((bdim.h, bdim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=front.device)
+    odt = torch.uint8 if rdr.out.dtype == 'u1' else torch.int16
+    out = ShardBuffers.get(front.device, ('out', id(mgr), bdim.h, bdim.w, odt), lambda: torch.empty((bdim.h, bdim.w, 4), dtype=odt, device=front.device))
     rdr.out.convert(mgr.fb, gprof, bdim)
     rdr.out.copy(mgr.fb, bdim, dev_out=out.data_ptr(), host=False)
     order_streams(mgr.fb, device, ctx_waits=False)                  # torch reads `out` behind the conversion
@@ -445,11 +489,12 @@ class DistComm(object):
     def __init__(self):
         self.rank, self.world = _world()
 
-    def exchange(self, acc2d, plan):
-        return exchange_bands(acc2d, plan, self.rank, self.world)
+    def exchange(self, acc2d, plan, padded=None):
+        return exchange_bands(acc2d, plan, self.rank, self.world, padded=padded)
 
     def gather_rows(self, mine):
-        allb = torch.empty((self.world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        allb = ShardBuffers.get(mine.device, ('allb', id(self), self.world, tuple(mine.shape), mine.dtype),
+                                lambda: torch.empty((self.world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device))
         if dist.get_backend() == 'nccl':
             dist.all_gather_into_tensor(allb, mine)
         else:
@@ -462,8 +507,8 @@ class DistComm(object):
 
 def sharded_frame_steps(mgr, rdr, gnm, gprof, tc, rank, world, device=None, copy=True, bands=True):
     """
-    One sample-sharded frame as a generator: it yields at the frame's collectives — ``('exchange', acc2d, plan)``,
-    to be answered (``send``) with ``(band, top)``; ``('gather', mine)``, answered with the gathered rows of all ranks;
+    One sample-sharded frame as a generator: it yields at the frame's collectives — ``('exchange', acc2d, plan, padded)``
+    (``padded``: the same accumulator with ``rows_per * world`` rows, or None), to be answered (``send``) with ``(band, top)``; ``('gather', mine)``, answered with the gathered rows of all ranks;
     ``('sum', acc)``, answered with anything once the accumulator has been summed in place — and returns
     ``(evt, h_out)`` (StopIteration.value).  queue_frame_sharded drives it with torch.distributed; a test can drive the
     generators of several virtual ranks of one process.  Nothing in here waits on the host: the native context's
@@ -484,6 +529,11 @@ def sharded_frame_steps(mgr, rdr, gnm, gprof, tc, rank, world, device=None, copy
     g = rdr._handle(fb)
     fid = C.c_uint32()
     _lib.check(lib.fl_frame_begin(fb.ctx, C.byref(fid)))
+    plan = band_plan(dim.ah, world) if (bands and band_path_ok(rdr.out, dim, [f.name for f in rdr.filts])) else None
+    if world > 1 and plan is not None and plan[0] * world != dim.ah:
+        # rows the ranks do not divide: this lane's accumulator gets room for rows_per * world rows (once: the buffers only
+        # grow), so that the reduce-scatter can run on it where it lies
+        _lib.check(lib.fl_reserve(fb.ctx, dim.w, plan[0] * world - 2 * fb.gutter))
     if copy:
         mgr._copy(rdr, gnm)
     marks = []
@@ -499,18 +549,22 @@ def sharded_frame_steps(mgr, rdr, gnm, gprof, tc, rank, world, device=None, copy
     _lib.check(lib.fl_iterate(fb.ctx, g, dim.w, dim.h, float(nsamps), mgr.fuse,
                               mgr.resolve_accum_mode(dim), C.byref(run)))
     mgr.last_nsamples = run.value
-    plan = band_plan(dim.ah, world) if (bands and band_path_ok(rdr.out, dim, [f.name for f in rdr.filts])) else None
     if world > 1 and plan is not None:
         # row bands: reduce-scatter + halo exchange, filter and convert the band, all-gather the 8-bit rows
         order_streams(fb, device, ctx_waits=False)                  # torch's stream behind the iterate + flush kernels
         mark('iterate')
-        acc = accumulator_tensor(fb, device, dim, wait=False).view(dim.ah, dim.astride * 4)
-        band, top = yield ('exchange', acc, plan)
-        mark('exchange')
         rows_per, ranges = plan
+        flat = accumulator_tensor(fb, device, None, wait=False)     # the whole buffer: the frame's rows, and the reserve behind them
+        rowf = dim.astride * 4
+        acc = flat[:dim.ah * rowf].view(dim.ah, rowf)
+        padded = flat[:rows_per * world * rowf].view(rows_per * world, rowf) if flat.numel() >= rows_per * world * rowf else None
+        band, top = yield ('exchange', acc, plan, padded)
+        mark('exchange')
         r0, r1 = ranges[rank]
         gut = fb.gutter
-        mine = torch.zeros((rows_per, dim.w, 4), dtype=torch.uint8 if rdr.out.dtype == 'u1' else torch.int16, device=acc.device)
+        odt = torch.uint8 if rdr.out.dtype == 'u1' else torch.int16
+        # (zeroed once: the rows a frame does not write — the frame's own gutter rows, in the first and the last band — are never written)
+        mine = ShardBuffers.get(acc.device, ('mine', id(mgr), rows_per, dim.w, odt), lambda: torch.zeros((rows_per, dim.w, 4), dtype=odt, device=acc.device))
         out, bdim = filter_band(mgr, rdr, gprof, dim, band, tc, device)
         # image rows of this band: accumulator rows [r0, r1) less the frame's own gutter rows
         y0, y1 = max(r0 - gut, 0), min(r1 - gut, dim.h)
@@ -525,6 +579,7 @@ def sharded_frame_steps(mgr, rdr, gnm, gprof, tc, rank, world, device=None, copy
         torch.from_numpy(h_out.view(np.uint8 if rdr.out.dtype == 'u1' else np.int16)).copy_(frame, non_blocking=True)
         mark('gather')
         evt = TorchFrameEvent(marks, keep=(allb, frame, out, mine, band))
+        fb._torch_stream_used = device                           # (Framebuffers.free waits for torch's stream too: the copy above is on it)
         fb._track(evt)
         return evt, h_out
     if world > 1:
@@ -554,7 +609,7 @@ def queue_frame_sharded(mgr, rdr, gnm, gprof, tc, device=None, copy=True, bands=
         while True:
             req = steps.send(reply)
             if req[0] == 'exchange':
-                reply = comm.exchange(req[1], req[2])
+                reply = comm.exchange(req[1], req[2], padded=req[3] if len(req) > 3 else None)
             elif req[0] == 'gather':
                 reply = comm.gather_rows(req[1])
             else:

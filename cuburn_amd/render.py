@@ -135,9 +135,14 @@ class Framebuffers(object):
         if self._ctx is None:
             lib = _lib.load()
             # The reference keeps its seed table for the manager's lifetime (cuburn/render.py:95-104).  Here a geometry switch
-            # re-creates the context and with it the RNG states: the generation count is mixed into the host seed, so that an
-            # animation whose samples per frame cross 2^28 does not replay the same streams after every switch.
-            seed = self.host_seed if not self.host_seed else (self.host_seed + 0x9E3779B1 * self.generation) & 0x7fffffff or 1
+            # re-creates the context and with it the RNG states: from the second context on the generation count is mixed into
+            # the host seed, so that an animation whose samples per frame cross 2^28 does not replay the same streams after
+            # every switch.  (As in the reference, a frame's noise depends on what this manager rendered before it — the RNG
+            # states persist across frames — and, after a switch, on how many switches there were; only the first context's
+            # streams are a function of the host seed alone.)
+            seed = self.host_seed
+            if seed and self.generation:
+                seed = (seed + 0x9E3779B1 * self.generation) & 0x7fffffff or 1
             seeds = np.ascontiguousarray(mwc.make_seeds(self.nwalkers, seed))
             ctx = C.c_void_p()
             _lib.check(lib.fl_ctx_create(self.device, self.stream, seeds.ctypes.data, self.nwalkers,
@@ -169,10 +174,11 @@ class Framebuffers(object):
             ntiles = ((dim.astride + 127) // 128) * ((dim.ah + 63) // 64)
             want = self.HUGE if ntiles > self.HUGE_FROM_TILES else self.WIDE if ntiles > self.WIDE_FROM_TILES else self.NARROW
             if want == self.NARROW:
-                # decided per FRAME from its sample count, so that (seed, frame) renders the same whatever was rendered
-                # before it, on whichever rank (a context that last held the other geometry is re-created: 1024 <-> 1536
-                # slots only changes when a job's samples per frame cross 2^28); without a sample count the small-image
-                # geometry in use is kept
+                # decided per FRAME from its sample count, so that the GEOMETRY a frame is rendered with does not depend on
+                # what was rendered before it, on whichever rank (a context that last held the other geometry is re-created:
+                # 1024 <-> 1536 slots only changes when a job's samples per frame cross 2^28; the re-created context's RNG
+                # streams do depend on the number of switches, see `ctx`); without a sample count the small-image geometry
+                # in use is kept
                 if nsamples is not None:
                     want = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
                 elif self._cfg in (self.NARROW, self.NARROW_FEW):
@@ -196,9 +202,18 @@ class Framebuffers(object):
         self._events = [r for r in self._events if r() is not None and r()._ms is None][-8:]
         self._events.append(weakref.ref(evt))
 
+    def _sync_torch(self):
+        """The sample-sharded path queues its last steps (all-gather, copy into the pinned frame buffer) on torch's stream:
+        before pinned memory or the context go away, that stream has to be through with them as well."""
+        dev = getattr(self, '_torch_stream_used', None)
+        if dev is not None:
+            import torch
+            torch.cuda.current_stream(dev).synchronize()
+
     def _drop_ctx(self):
         if self._ctx is not None:
             _lib.load().fl_ctx_sync(self._ctx)
+            self._sync_torch()
             for r in self._events:                      # resolve handles that still point into this context
                 evt = r()
                 if evt is not None:
@@ -221,6 +236,7 @@ class Framebuffers(object):
     def free(self):
         if self._ctx is not None:
             _lib.load().fl_ctx_sync(self._ctx)
+        self._sync_torch()
         self._host.clear()
         for p in self._pinned_ptrs:
             _lib.load().fl_host_free(p)

@@ -286,6 +286,12 @@ int fl_buffer_ptr_async(fl_ctx *ctx, fl_genome *g, int which, void **dev_ptr, si
  * (deferred filter steps included) happens before whatever the caller queues on `stream` next; ctx_waits = 1: everything queued
  * on `stream` so far happens before whatever the context queues on the lane next. */
 int fl_stream_dependency(fl_ctx *ctx, void *stream, int ctx_waits);
+/* Make the current lane's frame buffers large enough for a w x h image now (they only ever grow; what they held is lost when
+ * they do, so: before a frame's fl_iterate).  The sample-sharded path reserves the height that makes the accumulator's rows a
+ * multiple of the rank count: its reduce-scatter then runs on the accumulator where it lies (the rows behind the frame's own are
+ * summed and never looked at) instead of on a zero-padded copy per frame.  The reference's accumulator is allocated once, for the
+ * largest frame (cuburn/render.py:44-48, :107-113). */
+int fl_reserve(fl_ctx *ctx, uint32_t w, uint32_t h);
 
 /* Single-launch taps for bit-exact tests: run `nrounds` rounds (first `fuse` write-disabled)
  * for every slot with the given global round counter, no clears, no flush. */

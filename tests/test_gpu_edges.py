@@ -278,8 +278,8 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 def test_walker_geometry_follows_image_size():
     """A manager built without an explicit slot count uses 4-wave slots for small images — 1024 of
-    them for frames of up to 2^28 samples, 1536 above, decided per frame from its sample count (the same
-    (seed, frame) renders the same whatever the context rendered before) —
+    them for frames of up to 2^28 samples, 1536 above, decided per frame from its sample count (the GEOMETRY of a
+    frame does not depend on what the context rendered before; its RNG streams do, as in the reference) —
     8-wave slots from ~1440p up — 512 whose halves walk two temporal samples for frames of up to 2^28 samples, 1024 above —
     and 16-wave slots above 4K — 256 in quarters / 1024 — (the native context is re-created on the switch, genome handles follow)."""
     m = render.RenderManager(device=0, host_seed=5)

@@ -1163,6 +1163,80 @@ def test_sample_sharded_frame_never_waits_on_the_host(built):
         m.fb.free()
 
 
+def test_sample_sharded_frames_allocate_nothing_after_warm_up(built):
+    """The band path of a sample-sharded frame (distributed.sharded_frame_steps + exchange_bands' buffers) re-uses its device
+    tensors — band + halos, 8-bit band, gathered frame, conversion target — and runs the reduce-scatter on the accumulator where
+    it lies (fl_reserve: rows the ranks do not divide get room behind the frame's own rows instead of a zero-padded copy per
+    frame).  Twenty frames of two virtual ranks after two warm-up frames: torch's allocator is not asked for a single block
+    inside the library's steps (the stand-ins for the collectives, which are the test's own, are not counted), and the padded
+    view handed to the exchange aliases the accumulator."""
+    import torch
+    from cuburn_amd import distributed as D
+    gnm, prof = configs.cfg2(samples=2 ** 26)
+    prof = dict(prof, width=480, height=720)                      # ah = 752: two bands of 384 rows = 768, sixteen rows of reserve
+    gprof = profile.wrap(prof, gnm)
+    tc, world = 0.5, 2
+    mgrs = [render.RenderManager(device=0, host_seed=D.rank_seed(42, r)) for r in range(world)]
+    rdrs = [render.Renderer(gnm, gprof) for _ in range(world)]
+    dim = mgrs[0].fb.calc_dim(gprof.width, gprof.height)
+    plan = D.band_plan(dim.ah, world)
+    assert plan is not None
+    rows_per = plan[0]
+    nalloc = lambda: torch.cuda.memory_stats(0)['allocation.all.allocated']
+    counted = [0]
+
+    def step(fn, *a):
+        before = nalloc()
+        r = fn(*a)
+        counted[0] += nalloc() - before
+        return r
+
+    saw_padded = []
+
+    def frame():
+        gens = [D.sharded_frame_steps(mgrs[r], rdrs[r], gnm, gprof, tc, r, world, device=0) for r in range(world)]
+        reqs = [step(next, g) for g in gens]
+        assert all(q[0] == 'exchange' for q in reqs)
+        for q in reqs:
+            if q[3] is not None:
+                assert q[3].data_ptr() == q[1].data_ptr() and q[3].shape[0] == rows_per * world
+                saw_padded.append(True)
+        total = reqs[0][1] + reqs[1][1]
+        replies = []
+        for r in range(world):
+            hp = D.halo_plan(plan, r, dim.ah)
+            r0, r1 = plan[1][r]
+            replies.append((total[r0 - hp['top']:r1 + hp['bot']].clone(), hp['top']))
+        reqs = [step(g.send, rep) for g, rep in zip(gens, replies)]
+        allb = torch.cat([q[1] for q in reqs])
+        done = []
+        for g in gens:
+            try:
+                step(g.send, allb)
+                raise AssertionError('the generator should have finished')
+            except StopIteration as fin:
+                done.append(fin.value)
+        return done
+
+    for _ in range(2):
+        for evt, _h in frame():
+            evt.synchronize()
+    counted[0] = 0
+    last = None
+    for _ in range(20):
+        last = frame()
+    for evt, _h in last:
+        evt.synchronize()
+    assert counted[0] == 0, '%d device allocations inside the sharded frame steps of 20 frames' % counted[0]
+    if rows_per * world != dim.ah:
+        assert saw_padded, 'the accumulator was not handed out with its reserve'
+    a = np.array(last[0][1])
+    assert a.shape == (720, 480, 4) and a[..., :3].max() > 50
+    for m in mgrs:
+        m.fb.free()
+    D.ShardBuffers.clear()
+
+
 def test_sample_sharded_frame_two_virtual_ranks(built):
     """a frame split by samples.  Two contexts with the per-rank seeds each iterate
     their share; the accumulators are summed through the zero-copy torch views that the RCCL

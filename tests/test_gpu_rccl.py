@@ -99,6 +99,31 @@ for k in range(3):
     fg.submit()
 fg.flush()
 assert [g[0] for g in got] == [0, 1, 2] and [g[1] for g in got] == [(k + 1) * 270 * 480 * 4 for k in range(3)], got
+# 5. the two calls of the multi-rank paths that a world of one never reaches through the library: FrameGather's asynchronous gather,
+#    and the halo exchange's batched isend / irecv — here with this rank as its own peer (RCCL may refuse a self-peer: then the test
+#    says so and the call stays covered on gloo only, tests/test_cpu_dist.py)
+blk = torch.arange(2 * 270 * 480 * 4, device=dev, dtype=torch.int32).to(torch.uint8).reshape(2, 270, 480, 4)
+recv = [torch.empty_like(blk)]
+h = dist.gather(blk, recv, dst=0, async_op=True)                  # FrameGather._launch's call
+h.wait()
+torch.cuda.synchronize()
+assert torch.equal(recv[0], blk)
+a = torch.randn((224, 4 * 96), device=dev)
+b = torch.empty_like(a)
+try:
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)]):      # exchange_bands' call
+        w.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    print('RCCL_SELF_P2P_OK')
+except Exception as exc:                                          # noqa: BLE001 - any refusal is the answer this step records
+    print('RCCL_SELF_P2P_REFUSED: %%r' %% (exc,))
+# 6. exchange_bands on the accumulator's own reserve: rows the (pretended) ranks do not divide, handed over padded, no copy
+ah, rows_per = 300, 304
+acc_all = torch.randn((rows_per, 4 * 96), device=dev)
+band, top = D.exchange_bands(acc_all[:ah], (rows_per, [(0, ah)]), 0, 1, padded=acc_all)
+torch.cuda.synchronize()
+assert top == 0 and torch.equal(band, acc_all[:ah])
 dist.barrier()
 dist.destroy_process_group()
 print('RCCL_SINGLE_RANK_OK')
