@@ -128,6 +128,37 @@ def copy_bandwidth(torch, device):
     return 2 * n * 16 / (ms * 1e-3) / 1e9
 
 
+def hip_copy_bandwidth(device):
+    """The same 1 GiB float4 copy through the library's own kernel (fl_measure_copy: non-temporal loads and stores, HIP events)."""
+    import ctypes as C
+    from cuburn_amd import _lib
+    ms = C.c_float()
+    n = 1 << 30
+    _lib.check(_lib.load().fl_measure_copy(int(device), n, 10, C.byref(ms)))
+    return 2 * n / (ms.value * 1e-3) / 1e9
+
+
+def lib_sha256():
+    """sha256 of the library that is loaded: counter files under profiles/ name the library they were measured on."""
+    import hashlib
+    from cuburn_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+    except Exception:
+        return None
+
+
+def newest_profile(regex):
+    """Newest file under profiles/ whose NAME matches ``regex`` (group 1 = the round number), or None."""
+    import re
+    best = None
+    for f in os.listdir(os.path.join(REPO, 'profiles')):
+        m = re.match(regex + '$', f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.join(REPO, 'profiles', f))
+    return best[1] if best else None
+
+
 def launch_ranks(ngpus, argv):
     """
     `python bench.py --gpus N` with N > 1 outside a launcher: start N ranks ourselves (one process
@@ -369,58 +400,88 @@ def main():
     if rank == 0:
         dim = render.Framebuffers.calc_dim(w, h)
         nbins = dim.ah * dim.astride
-        copy_gbs = copy_bandwidth(torch, torch.device('cuda', local)) if world == 1 else None
+        # the box's streaming ceiling, two ways: the library's own copy kernel (float4, non-temporal, 1 GiB: the denominator of "DE >= 60 % of
+        # measured HBM bandwidth") and torch.Tensor.copy_ of the same size beside it (what rounds 1-5 divided by)
+        torch_copy_gbs = copy_bandwidth(torch, torch.device('cuda', local)) if world == 1 else None
+        copy_gbs = hip_copy_bandwidth(local) if world == 1 else None
         chain_s = (acc['iter_ms'] + acc['flush_ms']) * 1e-3
         chain = 16.0 * acc['samples'] / chain_s / 1e9 if chain_s > 0 else 0.0
         chain_ref_s = (acc_ref['iter_ms'] + acc_ref['flush_ms']) * 1e-3
-        traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
-        try:        # measured offline with tools/pmc_traffic.sh on this workload (KB units, reads x2)
-            import glob
-            # profiles/rNN_pmc_traffic.json is cfg2's; the other configs' files carry the config in their name
-            pat = 'r0*_pmc_traffic.json' if args.config == 'cfg2' else 'r0*_%s_pmc_traffic.json' % args.config
-            pmc_file = sorted(glob.glob(os.path.join(REPO, 'profiles', pat)))[-1]
-            pmc = json.load(open(pmc_file))
-            def kb(sub):
-                tot = 0.0
-                for k in pmc:
-                    if sub in k:
-                        c = pmc[k]
-                        # (launches of one frame differ in length when it has more than 1024 rounds: launches x MEAN is the frame's sum;
-                        # files of rounds 1-5a carry the median only)
-                        per = 'mean_per_launch' if 'mean_per_launch' in c['FETCH_SIZE'] else 'median_per_launch'
-                        tot += (2 * c['FETCH_SIZE'][per] + c['WRITE_SIZE'][per]) * 1024
-                return tot
-            if args.accum == 'binned':
-                # per LAUNCH in the file; a frame of more than 2^28 samples has several iterate / accumulate / flush launches
-                nl = max(acc['launches'], 1) / float(ksteps)
-                iter_bytes = int(kb('k_iter'))
-                traffic = int((iter_bytes + kb('k_accum_tiles') + kb('k_flush')) * nl)
-                de_traffic = int(kb('k_de_')) or None
-        except Exception:
-            traffic, iter_bytes, de_traffic, pmc_file = None, None, None, None
-        # Instruction-mix notes come from counter files committed under profiles/ (tools/pmc_sq.sh, tools/de_slot_budget.sh), never
-        # from literals here: the newest file measured on THIS config, named in the note, or no numbers at all.
-        def newest_profile(pattern):
-            import glob
-            found = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)))
-            return found[-1] if found else None
-        sq_file = newest_profile('r0*_sq_counters_k_iter_spec.json' if args.config == 'cfg2' else 'r0*_%s_sq_counters_k_iter_spec.json' % args.config)
-        if sq_file:
-            sq = json.load(open(sq_file))
-            iter_bound = ('instruction issue across the vector, scalar and branch units (DESIGN 4.1): %.0f M vector + %.0f M scalar instructions + %.0f M branches '
-                          'per launch, SQ counters of %s measured on %s (%s)'
-                          % (sq.get('SQ_INSTS_VALU', 0) / 1e6, sq.get('SQ_INSTS_SALU', 0) / 1e6, sq.get('SQ_INSTS_BRANCH', 0) / 1e6,
-                             'k_iter_spec', args.config, os.path.basename(sq_file)))
+        # Counter-derived figures come from files committed under profiles/ (tools/pmc_traffic.sh, tools/pmc_sq.sh,
+        # tools/de_slot_budget.sh), never from literals here, and only from a file that names THIS library (sha256 of the .so it
+        # was measured on): a kernel change that was not re-profiled prints null and the reason instead of last round's bytes.
+        sha = lib_sha256()
+        tag = '' if args.config == 'cfg2' else args.config + '_'
+        traffic, iter_bytes, de_traffic, traffic_note = None, None, None, None
+        pmc_file = newest_profile(r'r(\d+)_%spmc_traffic\.json' % tag)
+        if pmc_file is None:
+            traffic_note = 'no TCC counter file for %s under profiles/ (tools/pmc_traffic.sh)' % args.config
         else:
-            iter_bound = 'no SQ counter file for %s under profiles/ (tools/pmc_sq.sh)' % args.config
-        de_file = newest_profile('r0*_de_slot_budget.txt' if args.config == 'cfg2' else 'r0*_%s_de_slot_budget.txt' % args.config)
-        de_bound = ('vector-ALU issue slots: per-direction slot budget and the one rate that reproduces the kernels\' times, measured on %s, in %s; '
-                    '512 B/px is the algorithmic byte count of the reference pass structure' % (args.config, os.path.basename(de_file))) if de_file else \
-                   ('no slot budget measured on %s under profiles/ (tools/de_slot_budget.sh); 512 B/px is the algorithmic byte count of the reference pass structure' % args.config)
+            try:        # KB units, reads x 2 (MI355X_MICROARCH.md)
+                pmc = json.load(open(pmc_file))
+                if pmc.get('_meta', {}).get('lib_sha256') != sha:
+                    traffic_note = '%s was measured on another build of the library (sha256 %s..., loaded %s...): re-run tools/pmc_traffic.sh' % (
+                        os.path.basename(pmc_file), str(pmc.get('_meta', {}).get('lib_sha256'))[:12], str(sha)[:12])
+                else:
+                    def kb(sub):
+                        tot = 0.0
+                        for k in pmc:
+                            if sub in k and 'FETCH_SIZE' in pmc[k]:
+                                c = pmc[k]
+                                # (launches of one frame differ in length when it has more than 1024 rounds: launches x MEAN is the frame's sum)
+                                per = 'mean_per_launch' if 'mean_per_launch' in c['FETCH_SIZE'] else 'median_per_launch'
+                                tot += (2 * c['FETCH_SIZE'][per] + c['WRITE_SIZE'][per]) * 1024
+                        return tot
+                    if args.accum == 'binned':
+                        # per LAUNCH in the file; a frame of more than 2^28 samples has several iterate / accumulate / flush launches
+                        nl = max(acc['launches'], 1) / float(ksteps)
+                        iter_bytes = int(kb('k_iter'))
+                        traffic = int((iter_bytes + kb('k_accum_tiles') + kb('k_flush')) * nl)
+                    de_traffic = int(kb('k_de_')) or None
+            except Exception as exc:
+                traffic, iter_bytes, de_traffic, traffic_note = None, None, None, 'unreadable %s: %r' % (os.path.basename(pmc_file), exc)
         launches = max(acc['launches'], 1)
-        big_ms = (acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps
         iter_launch_s = acc['iter_ms'] * 1e-3 / launches
         de_s = (acc['de_ms'] + acc['de_finish_ms']) * 1e-3 / ksteps
+        VALU_NS = 1.21              # one vector-ALU wave instruction per SIMD, eight waves resident (tools/valu_bench.hip, profiles/r03_valu_lds_microbench.txt)
+        sq_file = newest_profile(r'r(\d+)_%ssq_counters_k_iter_spec\.json' % tag)
+        iter_valu_frac = None
+        if sq_file:
+            sq = json.load(open(sq_file))
+            if sq.get('_lib_sha256') == sha:
+                iter_bound = ('instruction issue across the vector, scalar and branch units: %.0f M vector + %.0f M scalar instructions + %.0f M branches '
+                              'per launch, SQ counters of k_iter_spec measured on %s with this library (%s)'
+                              % (sq.get('SQ_INSTS_VALU', 0) / 1e6, sq.get('SQ_INSTS_SALU', 0) / 1e6, sq.get('SQ_INSTS_BRANCH', 0) / 1e6,
+                                 args.config, os.path.basename(sq_file)))
+                if iter_launch_s > 0:
+                    # flame-independent yardstick: the share of the launch that the vector ALUs of 1024 SIMDs need for the kernel's own instructions
+                    iter_valu_frac = round(sq.get('SQ_INSTS_VALU', 0) * VALU_NS * 1e-9 / 1024.0 / iter_launch_s, 4)
+            else:
+                iter_bound = '%s was measured on another build of the library: no counter figures (tools/pmc_sq.sh)' % os.path.basename(sq_file)
+        else:
+            iter_bound = 'no SQ counter file for %s under profiles/ (tools/pmc_sq.sh)' % args.config
+        de_file = newest_profile(r'r(\d+)_%sde_slot_budget\.txt' % tag)
+        de_valu_frac, de_bound = None, None
+        if de_file:
+            txt = open(de_file).read()
+            if ('lib_sha256: %s' % sha) in txt:
+                # slot-equivalents per launched lane, summed over the eight directions' shipped kernels ("full" rows, column 8)
+                slots = sum(float(l.split()[7]) for l in txt.splitlines() if len(l.split()) >= 10 and l.split()[1] == 'full' and l.split()[0].isdigit())
+                if de_s > 0 and slots > 0:
+                    de_valu_frac = round(slots * (nbins / 64.0) / 1024.0 * VALU_NS * 1e-9 / de_s, 4)
+                de_bound = ('vector-ALU issue slots: %.0f slot-equivalents per pixel over the eight directions (%s, measured on %s with this library); '
+                            'valu_frac = that budget at %.2f ns per slot and SIMD / the measured time; 512 B/px is the algorithmic byte count of the '
+                            'reference pass structure' % (slots, os.path.basename(de_file), args.config, VALU_NS))
+            else:
+                de_bound = '%s was measured on another build of the library: no slot budget (tools/de_slot_budget.sh); 512 B/px is the algorithmic byte count of the reference pass structure' % os.path.basename(de_file)
+        else:
+            de_bound = 'no slot budget measured on %s under profiles/ (tools/de_slot_budget.sh); 512 B/px is the algorithmic byte count of the reference pass structure' % args.config
+        big_ms = (acc['iter_ms'] + acc['flush_ms'] + acc['filter_ms']) / ksteps
+        try:        # the library's own rule for FLAME_LANES (flame_abi.hip: 1..4, anything else 2)
+            lanes = int(os.environ.get('FLAME_LANES', '2'))
+            lanes = lanes if 1 <= lanes <= 4 else 2
+        except ValueError:
+            lanes = 2
         de_gbs = 512.0 * nbins / de_s / 1e9 if de_s > 0 else 0.0            # 64 B/px/direction x 8
         out = {
             'metric': 'Msamples/s into 1920x1080 histogram + DE-filter GB/s vs HBM roofline',
@@ -436,7 +497,7 @@ def main():
                             % (args.config, gprof.width, gprof.height, len(gnm['xforms']), samples_per_frame if args.shard == 'frames' else job_samples_per_step),
                        'walker_waves': mgr.fb.nw, 'walker_slots': mgr.fb.nslots, 'temporal_samples': mgr.fb.ntemporal,
                        'samples_per_frame': samples_per_frame if args.shard == 'frames' else job_samples_per_step,
-                       'stream_lanes': {'lanes': 2, 'sum_of_big_kernels_ms': round(big_ms, 4),
+                       'stream_lanes': {'lanes': lanes, 'sum_of_big_kernels_ms': round(big_ms, 4),
                                         'overlap_ms_per_frame': round(big_ms - elapsed / args.steps * 1e3, 4),
                                         'note': 'sum_of_big_kernels_ms = iterate + accumulate + flush + filter kernels of a frame timed alone on one lane; '
                                                 'overlap_ms_per_frame = that sum minus ms_per_step: what the second lane hides (kernels of frame k+1 '
@@ -457,11 +518,11 @@ def main():
                        'sample_shard_phases_ms': sample_phases},
             'roofline': {'bound': 'hbm', 'kernel': 'k_iter + k_accum_tiles + k_flush (iterate chain: the 8-byte packed-cell RMW per sample)',
                          'achieved': round(chain, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(chain / HBM_PEAK_GBS, 5),
-                         'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file else None,
-                         'traffic_measured_in_this_run': False,
+                         'traffic': traffic, 'traffic_source': os.path.basename(pmc_file) if pmc_file and traffic is not None else None,
+                         'traffic_measured_in_this_run': False, 'traffic_note': traffic_note, 'library_sha256': sha,
                          'algorithmic_bytes_per_frame': int(16 * acc['samples'] / ksteps),
                          'chain_ms_per_frame': round(chain_s / ksteps * 1e3, 4),
-                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': iter_bound,
+                         'k_iter': {'avg_launch_ms': round(iter_launch_s * 1e3, 4), 'bound': iter_bound, 'valu_issue_frac': iter_valu_frac,
                                     'measured_bytes_per_launch': iter_bytes,
                                     'measured_gbps': round(iter_bytes / iter_launch_s / 1e9, 1) if iter_bytes else None,
                                     'msamples_per_s': round(acc['samples'] / (acc['iter_ms'] * 1e-3) / 1e6, 1) if acc['iter_ms'] > 0 else 0.0},
@@ -474,6 +535,9 @@ def main():
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,
                           'frac_of_copy': round(de_gbs / copy_gbs, 5) if copy_gbs else None,
+                          'torch_copy_gbps': round(torch_copy_gbs, 1) if torch_copy_gbs else None,
+                          'frac_of_torch_copy': round(de_gbs / torch_copy_gbs, 5) if torch_copy_gbs else None,
+                          'valu_frac': de_valu_frac,
                           'frac_of_achievable_6300': round(de_gbs / HBM_ACHIEVABLE_GBS, 5),
                           'traffic': de_traffic,
                           'bound': de_bound},

@@ -51,6 +51,7 @@ _SIGS = {
                              C.POINTER(C.c_uint32)]),
     'fl_timings_detail': (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 6)]),
     'fl_launch_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32 * 4)]),
+    'fl_measure_copy': (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     'fl_read_buffer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     'fl_write_buffer': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     'fl_buffer_ptr': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -154,4 +154,48 @@ def cfg5(samples=2 ** 32):
     return gnm, prof
 
 
+def allvars():
+    """Not a BASELINE config: a genome that uses EVERY variation — twelve xforms of eight variations each in table order, every
+    parameter of every parametric variation away from its default (some animated), post affines on every other xform, a final
+    xform with its own post affine — at a small size.  The packer's knot rows for it are pinned to the reference's
+    GenomePacker.pack (tests/golden/packer.json, tests/golden/make_golden.py section 4: cuburn/code/interp.py:125-232,
+    cuburn/genome/variations.py:7-16); the config genomes alone reach 15 of the 95 variations' parameter rows."""
+    from .genome import variations as V
+    names = [name for _, name, _ in V._TABLE]
+    rs = np.random.RandomState(95)
+    xforms = {}
+    for i in range(0, len(names), 8):
+        vs = {}
+        for j, v in enumerate(names[i:i + 8]):
+            vd = {'weight': round(0.05 + 0.02 * j, 4)}
+            for k, (pn, (default, interp)) in enumerate(sorted((pn, pd) for pn, pd in V.var_params[v].items() if pn != 'weight')):
+                val = round(float(default) + 0.13 * (k + 1) + 0.01 * j, 4)
+                # every third parameter moves during the frame (animation format [p0, v0, p1, v1]; mag-domain ones stay positive)
+                vd[pn] = [val, 0.1, round(val + 0.25, 4), 0.1] if (k + j) % 3 == 0 else val
+            vs[v] = vd
+        key = '%02d' % (i // 8)
+        xf = {'weight': float(rs.uniform(0.5, 1.5)), 'color': (i // 8) / 11.0, 'color_speed': 0.3 + 0.02 * (i // 8),
+              'pre_affine': _affine(float(rs.uniform(-180, 180)), float(rs.uniform(0.5, 0.85)),
+                                    float(rs.uniform(-0.6, 0.6)), float(rs.uniform(-0.4, 0.4))),
+              'variations': vs}
+        if (i // 8) % 2 == 1:
+            xf['post_affine'] = _affine(float(rs.uniform(-30, 30)), float(rs.uniform(0.9, 1.1)), float(rs.uniform(-0.1, 0.1)), float(rs.uniform(-0.1, 0.1)))
+        xforms[key] = xf
+    xforms['03']['pre_affine']['angle'] = [20.0, 30.0, 50.0, 30.0]
+    gnm = {
+        'type': 'animation', 'name': 'allvars-95',
+        'camera': {'center': {'x': 0.05, 'y': -0.1}, 'rotation': [5.0, 8.0, 13.0, 8.0], 'scale': 0.21},
+        'time': {'duration': 1, 'frame_width': 1.0},
+        'palette': [_pal(0.0, fire_palette()), _pal(1.0, ice_palette())],
+        'xforms': xforms,
+        'final_xform': {'color': 0.5, 'color_speed': 0.1, 'pre_affine': _affine(3.0, 1.01, 0.02, -0.01),
+                        'post_affine': _affine(-2.0, 0.99, 0.0, 0.01),
+                        'variations': {'linear': {'weight': 0.9}, 'curl': {'weight': 0.1, 'c1': 0.3, 'c2': [0.1, 0.0, 0.2, 0.0]}}},
+    }
+    prof = {'width': 640, 'height': 360, 'spp': 2 ** 22 / (640.0 * 360.0), 'fps': 24, 'duration': 2,
+            'frame_width': 1.0, 'output': {'type': 'raw'},
+            'filter_order': ['bilateral', 'logscale', 'colorclip']}
+    return gnm, prof
+
+
 CONFIGS = {'cfg1': cfg1, 'cfg2': cfg2, 'cfg3': cfg3, 'cfg4': cfg4, 'cfg5': cfg5}

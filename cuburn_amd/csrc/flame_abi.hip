@@ -1008,6 +1008,14 @@ int fl_launch_stats(fl_ctx *c, uint32_t out[4])
     return FL_OK;
 }
 
+int fl_measure_copy(int device, size_t nbytes, int iters, float *ms)
+{
+    REQUIRE(ms && iters > 0 && nbytes >= 16, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    if (launch_measure_copy(nbytes, iters, ms)) return fail(FL_E_HIP, "copy measurement (allocation of 2 x nbytes, or the launch)", __FILE__, __LINE__);
+    return FL_OK;
+}
+
 int fl_timings(fl_ctx *c, float *iter_ms, float *flush_ms, float *filter_ms, uint32_t *nlaunch)
 {
     REQUIRE(c, "null ctx");

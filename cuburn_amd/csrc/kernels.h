@@ -90,6 +90,8 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
 // output.hip
 void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng, uint32_t nrng, int fmt, void *dst);
 
+int launch_measure_copy(size_t nbytes, int iters, float *ms);      // the device's streaming copy rate (fl_measure_copy)
+
 // sort.hip: one stable radix pass (nbits <= 10 at lo_bit) over n keys; hist = scratch of
 // sort_scratch_words() words, chunk_tot = *chunk_words words (the last one receives the number of keys kept)
 int launch_sort_pass(hipStream_t st, uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t lo_bit, uint32_t nbits,

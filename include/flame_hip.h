@@ -253,6 +253,11 @@ int fl_timings_detail(fl_ctx *ctx, float ms[6]);
  * genome's structure (hipRTC; the counterpart of the module the reference compiles per genome, cuburn/render.py:232-236),
  * out[1] launches of the precompiled interpreter kernel (the fallback); out[2] walker slots, out[3] waves per slot. */
 int fl_launch_stats(fl_ctx *ctx, uint32_t out[4]);
+/* The device's streaming ceiling as this library can reach it: a float4 copy of `nbytes` (read + write; at least 1 GiB each
+ * way, so that the 256 MiB Infinity Cache does not serve it) with non-temporal loads and stores, `iters` launches between two HIP
+ * events; *ms = milliseconds per copy.  The denominator of bench.py's "DE >= 60 % of measured HBM bandwidth" (BASELINE.json,
+ * SURVEY.md 8d); the reference has no such measurement. */
+int fl_measure_copy(int device, size_t nbytes, int iters, float *ms);
 
 /* ---- debug taps (tests only): read/write device state ---- */
 enum {

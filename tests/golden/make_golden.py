@@ -216,8 +216,8 @@ def main():
 
     # ---- 4. Packer: per-path knot rows of GenomePacker.pack for the config genomes (interp.py:207-232)
     packs = {}
-    for name in ('cfg1', 'cfg2', 'cfg3', 'cfg5'):
-        gnm, prof = configs.CONFIGS[name]()
+    for name in ('cfg1', 'cfg2', 'cfg3', 'cfg5', 'allvars'):           # allvars: every variation, every parameter (configs.allvars)
+        gnm, prof = configs.allvars() if name == 'allvars' else configs.CONFIGS[name]()
         packer, lib = ref_iter.mkiterlib(gnm)
         util.assemble_code(lib)
         times, knots = packer.pack(gnm)

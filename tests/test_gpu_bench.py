@@ -37,9 +37,39 @@ def test_bench_single_gpu_line(built):
     assert 0 < out['roofline']['frac'] < 1 and out['roofline']['bound'] == 'hbm'
     assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['value'] > 0
     assert out['config']['samples_per_frame'] >= 2 ** 28
-    # counter-derived notes name the config they were measured on and the profiles/ file they come from (no literals in bench.py)
-    assert 'cfg2' in out['roofline']['k_iter']['bound'] and 'sq_counters_k_iter_spec.json' in out['roofline']['k_iter']['bound']
-    assert 'cfg2' in out['de_filter']['bound'] and 'de_slot_budget' in out['de_filter']['bound']
+    # counter-derived notes name the profiles/ file they come from (no literals in bench.py) and, when the file was measured on the
+    # library that is loaded, the config; a file of another build yields no figures (next test)
+    assert 'sq_counters_k_iter_spec.json' in out['roofline']['k_iter']['bound'] and 'de_slot_budget' in out['de_filter']['bound']
+    for note, frac in ((out['roofline']['k_iter']['bound'], out['roofline']['k_iter']['valu_issue_frac']), (out['de_filter']['bound'], out['de_filter']['valu_frac'])):
+        assert ('another build' in note and frac is None) or ('cfg2' in note and 0 < frac < 1.5), (note, frac)
+    if out['roofline']['traffic'] is not None:
+        meta = json.load(open(os.path.join(REPO, 'profiles', out['roofline']['traffic_source'])))['_meta']
+        assert meta['lib_sha256'] == out['roofline']['library_sha256'] and out['roofline']['traffic_note'] is None
+    else:
+        assert out['roofline']['traffic_note']
+    # the DE's denominator: the library's own non-temporal copy kernel, torch's copy_ beside it
+    de = out['de_filter']
+    assert de['measured_copy_gbps'] > 2000 and de['torch_copy_gbps'] > 2000
+    assert abs(de['frac_of_copy'] - de['gbps'] / de['measured_copy_gbps']) < 1e-3
+    assert out['config']['stream_lanes']['lanes'] == 2
+
+
+def test_counter_files_are_quoted_only_for_the_library_they_were_measured_on(built, tmp_path):
+    """roofline.traffic, k_iter.valu_issue_frac and de_filter.valu_frac come from counter files under profiles/ that carry the sha256
+    of the library they were measured on (tools/pmc_traffic.sh, pmc_sq.sh, de_slot_budget.sh).  Another build of the library — here the
+    same library with one byte appended — must print none of them, and say why."""
+    import shutil
+    from cuburn_amd import _lib
+    lib2 = str(tmp_path / 'libflame_hip_other.so')
+    shutil.copy(_lib.LIB_PATH, lib2)
+    with open(lib2, 'ab') as f:
+        f.write(b'\0')
+    out = run_bench(['--gpus', '1', '--cpu-seconds', '0'] + SMALL, env={'FLAME_HIP_LIB': lib2})
+    r = out['roofline']
+    assert r['traffic'] is None and r['traffic_source'] is None and 'another build' in r['traffic_note']
+    assert r['k_iter']['valu_issue_frac'] is None and 'another build' in r['k_iter']['bound']
+    assert out['de_filter']['valu_frac'] is None and out['de_filter']['traffic'] is None
+    assert 0 < r['frac'] < 1                      # what is measured live stays
 
 
 def test_bench_counter_notes_belong_to_the_config(built):

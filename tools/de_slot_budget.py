@@ -25,6 +25,8 @@ def counters(b):
     return out
 dur = {b: durations(b) for b in ('full', 'stage', 'taps')}
 cnt = {b: counters(b) for b in ('full', 'stage', 'taps')}
+import hashlib, os
+print('# lib_sha256: %s' % hashlib.sha256(open(os.environ.get('DE_FULL_LIB', 'cuburn_amd/_lib/libflame_hip.so'), 'rb').read()).hexdigest())      # the "full" build: bench.py quotes this budget for that library only
 print('# DE slot budget (tools/de_slot_budget.sh): vector-ALU instructions per OUTPUT PIXEL = per launched lane (SQ_INSTS_VALU / waves), by build')
 print('# slot-equivalents = VALU + %.1f * transcendental (a transcendental holds the ALU %.1f slots).  stage = until the planes are staged,' % (TRANS_SLOTS - 1, TRANS_SLOTS))
 print('# taps = tap loop + epilogue on unstaged LDS; full = the shipped kernel.  us = rocprofv3 average duration.')

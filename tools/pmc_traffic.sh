@@ -18,7 +18,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         vals = sorted(d.values())
         out.setdefault(k, {})[ctr] = {"n": len(vals), "median_per_launch": vals[len(vals) // 2], "max": vals[-1],
                                       "mean_per_launch": sum(vals) / len(vals)}       # (a frame's launches differ in length: launches x mean = the frame)
+import hashlib, os, subprocess
+lib = os.environ.get("FLAME_HIP_LIB", "cuburn_amd/_lib/libflame_hip.so")
+out["_meta"] = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "lib": lib, "bench_args": os.environ.get("BENCH_ARGS", "")}
 json.dump(out, open("gpurun_out/pmc_${tag}_traffic.json", "w"), indent=1, sort_keys=True)
-for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("WRITE_SIZE", {}).get("median_per_launch", 0)):
+for k, v in sorted(((k, v) for k, v in out.items() if k != "_meta"), key=lambda kv: -kv[1].get("WRITE_SIZE", {}).get("median_per_launch", 0)):
     print(k[:60].ljust(60), {c: round(x["median_per_launch"], 1) for c, x in v.items()})
 PY
