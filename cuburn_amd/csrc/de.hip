@@ -907,8 +907,9 @@ static void launch_de_dir_one(hipStream_t st, fl_dim d, float4 *Nout, const floa
                        cs2, ads, dpow, gspeed, tiles_y, ntiles, tiles_x, magic, tail);
 }
 
-// in_mode (pattern 0 only): 0 = N holds the normalised image, 1 = the raw accumulator, 2 = the raw YUV
-// accumulator.  tail (pattern 7 only, may be null): un-normalise + the tone filters riding along.
+// in_mode (pattern 0 only; ignored by the others): 1 = N is the raw accumulator, 2 = the raw YUV accumulator (yuv -> rgb first) — the first
+// direction always normalises as it stages; anything else is refused (a "0 = already normalised" form existed until round 5: a caller
+// that still relied on it would get a second normalisation).  tail (pattern 7 only, may be null): un-normalise + the tone filters riding along.
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
                    float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode, const DeTail *tail)
 {
@@ -947,7 +948,9 @@ void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const fl
     tl.order = order;
 #define DE(P, I, O) launch_de_dir_one<P, I, O>(st, d, Nout, N, kc, spk, cs2, ads, dpow, gspeed, tl)
     switch (pattern) {
-    case 0: if (in_mode == 2) DE(0, 2, 0); else DE(0, 1, 0); break;          // the first direction normalises the accumulator (after yuv -> rgb, if asked)
+    case 0:                                                                   // the first direction normalises the accumulator (after yuv -> rgb, if asked)
+        if (in_mode == 2) DE(0, 2, 0); else if (in_mode == 1) DE(0, 1, 0); else abort();
+        break;
     case 1: DE(1, 0, 0); break;
     case 2: DE(2, 0, 0); break;
     case 3: DE(3, 0, 0); break;

@@ -82,7 +82,7 @@ void launch_logencode(hipStream_t st, fl_dim d, float4 *dst, const float4 *src, 
 // tone filters that ride along with the last DE direction (filters.py default chains: DE -> logscale -> colorclip)
 struct DeTail { int do_log; float k1, k2; int do_clip; float vib, highpow, gam, lin, lingam; int order; };
 void launch_de_dir(hipStream_t st, fl_dim d, int pattern, float4 *Nout, const float4 *N, const float *coefs7,
-                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 0, const DeTail *tail = nullptr);
+                   float sstd, float cstd, float dstd, float dpow, float gspeed, int in_mode = 1, const DeTail *tail = nullptr);
 // (pattern 0 normalises the raw accumulator as it stages it — in_mode 1, or 2: after yuv -> rgb —; pattern 7 un-normalises and
 // applies `tail`'s tone filters as it stores; round 5 removed the separate normalise / finish kernels, the persistent and the
 // overlapped eight-direction launches of round 4 (de_chain.hip: git history, commit 58f1875) and round 1's blur + packed-math pair)
