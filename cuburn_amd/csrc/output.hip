@@ -115,19 +115,14 @@ void launch_f32_to_rgba(hipStream_t st, fl_dim d, const float4 *src, fl_mwc *rng
 }
 
 // ---- measurement: the streaming copy rate of the device (fl_measure_copy) -------------------------------------------
-// float4 per lane, four in flight per thread, non-temporal both ways (the data is touched once), 2048 workgroups of 256: eight per CU.
+// One float4 per thread, non-temporal both ways (the data is touched once), consecutive workgroups on consecutive 4 KB: 6.2-6.4 TB/s.
+// (tools/copy_bench.hip, profiles/r06_copy_bench.txt: the same copy as a grid-stride loop of 1024-65536 workgroups runs at 4.4-5.4 TB/s —
+// every workgroup then strides through the whole GiB —, hipMemcpyDtoD and torch's copy_ at 5.2-5.5.)
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_copy_nt(f32x4_ *__restrict__ dst, const f32x4_ *__restrict__ src, size_t n4)
 {
-    const size_t stride = (size_t)gridDim.x * 256u;
-    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4_ a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const f32x4_ c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
-    }
-    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 int launch_measure_copy(size_t nbytes, int iters, float *ms)
@@ -136,11 +131,12 @@ int launch_measure_copy(size_t nbytes, int iters, float *ms)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = -1;
     const size_t n4 = nbytes / 16;
-    if (hipMalloc(&a, n4 * 16) == hipSuccess && hipMalloc(&b, n4 * 16) == hipSuccess && hipMemset(a, 1, n4 * 16) == hipSuccess &&
+    const unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (n4 / 256 < 0x7fffffffu && hipMalloc(&a, n4 * 16) == hipSuccess && hipMalloc(&b, n4 * 16) == hipSuccess && hipMemset(a, 1, n4 * 16) == hipSuccess &&
         hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-        for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(k_copy_nt, dim3(2048), dim3(256), 0, 0, (f32x4_ *)b, (const f32x4_ *)a, n4);
+        for (int k = 0; k < 2; ++k) hipLaunchKernelGGL(k_copy_nt, dim3(blocks), dim3(256), 0, 0, (f32x4_ *)b, (const f32x4_ *)a, n4);
         hipEventRecord(e0, 0);
-        for (int k = 0; k < iters; ++k) hipLaunchKernelGGL(k_copy_nt, dim3(2048), dim3(256), 0, 0, (f32x4_ *)b, (const f32x4_ *)a, n4);
+        for (int k = 0; k < iters; ++k) hipLaunchKernelGGL(k_copy_nt, dim3(blocks), dim3(256), 0, 0, (f32x4_ *)b, (const f32x4_ *)a, n4);
         hipEventRecord(e1, 0);
         float t = 0.0f;
         if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess) { *ms = t / (float)iters; rc = 0; }

@@ -4,7 +4,7 @@
 #   stage   -DDE_X_STOP_AFTER=4  (a workgroup ends when its planes are staged: loads, blurs, tap terms)
 #   taps    -DDE_X_TAPSONLY      (a workgroup runs the tap loop + epilogue on whatever its LDS holds)
 # (the timing builds produce garbage pictures).  Durations: rocprofv3 --kernel-trace --stats; instructions: SQ counters, separate passes.
-# usage: tools/de_slot_budget.sh [bench args]     -> gpurun_out/r05_de_slot_budget.txt
+# usage: tools/de_slot_budget.sh [bench args]     -> gpurun_out/${DE_BUDGET_TAG:-r06}_de_slot_budget.txt (with the sha256 of the full library: bench.py quotes the budget for that library only)
 export TMPDIR=/tmp FLAME_LANES=1
 declare -A LIB=([full]=cuburn_amd/_lib/libflame_hip.so [stage]=cuburn_amd/_lib/libflame_hip_xstage.so [taps]=cuburn_amd/_lib/libflame_hip_xtaps.so)
 python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --preheat-seconds 2 --min-timed-frames 0 "$@" > /dev/null 2>&1
@@ -17,5 +17,5 @@ for b in full stage taps; do
     i=$((i+1))
   done
 done
-python3 tools/de_slot_budget.py gpurun_out > gpurun_out/r05_de_slot_budget.txt
-cat gpurun_out/r05_de_slot_budget.txt
+python3 tools/de_slot_budget.py gpurun_out > gpurun_out/${DE_BUDGET_TAG:-r06}_de_slot_budget.txt
+cat gpurun_out/${DE_BUDGET_TAG:-r06}_de_slot_budget.txt
