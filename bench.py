@@ -446,7 +446,11 @@ def main():
         VALU_NS = 1.21              # one vector-ALU wave instruction per SIMD, eight waves resident (tools/valu_bench.hip, profiles/r03_valu_lds_microbench.txt)
         sq_file = newest_profile(r'r(\d+)_%ssq_counters_k_iter_spec\.json' % tag)
         iter_valu_frac = None
-        if sq_file:
+        if args.accum != 'binned':
+            # (the counter files are the binned path's: the direct-atomic kernel is another kernel)
+            iter_bound = ('direct 64-bit packed atomics, one per sample: the scattered-atomic ceiling of the memory side '
+                          '(23.7 G atomics/s whatever the footprint, profiles/r01_atomic_microbench.txt)')
+        elif sq_file:
             sq = json.load(open(sq_file))
             if sq.get('_lib_sha256') == sha:
                 iter_bound = ('instruction issue across the vector, scalar and branch units: %.0f M vector + %.0f M scalar instructions + %.0f M branches '

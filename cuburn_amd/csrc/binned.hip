@@ -40,6 +40,17 @@ __device__ __forceinline__ void spill_cell(u64 cur, uint32_t gi, float *__restri
 #endif
 __device__ HOT_GROUP_INLINE void hot_group(u64 v, unsigned long long grp, uint32_t gi, float *__restrict__ out4)
 {
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, sh), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), sh);
+        v += ((u64)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(grp)) spill_cell(v, gi, out4);
+}
+
+// the same for k_accum_tiles_p3
+__device__ HOT_GROUP_INLINE void hot_group_sw(u64 v, unsigned long long grp, uint32_t gi, float *__restrict__ out4)
+{
     // (xor 1 .. 16 as ds_swizzle with the pattern in the instruction: the lane addresses of six __shfl_xor are loop-invariant, the
     // compiler computes them in front of the record loop and keeps — or spills — five registers for a path that is almost never taken)
 #define HOT_XOR(sh) do { const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)v, 0x1f | ((sh) << 10)), \
@@ -94,6 +105,9 @@ __device__ __forceinline__ uint32_t wave_incl_maxscan(uint32_t v) {             
 #endif
 #ifndef ACC_DIR_AHEAD
 #define ACC_DIR_AHEAD 1        /* a group's directory words are requested one group ahead (the first group's before the tile is zeroed) */
+#endif
+#ifndef ACC_BYTE_MARKS
+#define ACC_BYTE_MARKS 1       /* run lookup: one LDS exchange of byte marks per step + ds_bpermute, instead of one exchange of word marks per 64 records */
 #endif
 #ifndef ACC_LOAD_MOD
 #define ACC_LOAD_MOD ""        /* cache policy of the record loads (" nt", " sc1", ...): experiment, see profiles/r03_accum_cache_policy.txt */
@@ -182,31 +196,30 @@ __device__ __forceinline__ void add_tile_to_cells(const u64 *tile, u64 *__restri
     }
 }
 
+// One record per 32-bit log word: 256x64 tiles, and 128x64 tiles of a build without FL_LOG_PACK3 (the packed log has its own kernel below).
+// This is round 5's kernel, unchanged (a round-6 refactoring of it for a templated packed form measured +4.8 % at 8K and was taken back).
 // TWL: log2 of the tile width (7: 128x64 tiles = 64 KB of LDS cells, two workgroups per CU;
 // 8: 256x64 tiles = 128 KB, for images with more than 2047 narrow tiles)
-// One record per 32-bit log word: 256x64 tiles, and 128x64 tiles of a build without FL_LOG_PACK3 (the packed log has its own kernel below).
 // 80 SGPRs including VCC etc.: two 16-wave workgroups per CU need 8 waves per SIMD, and a CU of this GPU holds
 // 8 waves per SIMD only up to 80 SGPRs per wave (measured: tools/occupancy_probe.hip,
 // profiles/r03_occupancy_probe.txt; the compiler's table and the occupancy API say 96)
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 template <uint32_t TWL>
 __global__ void __launch_bounds__(TWL == 7u ? ACC_THREADS : 1024, TWL == 7u ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir,
               const u64 *__restrict__ palette, u64 *__restrict__ atom, float *__restrict__ out4,
-              uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_stride,
+              uint32_t tiles_x, uint32_t nparts, uint32_t nbatch_total, uint32_t batch_records,
               uint32_t nslots, uint32_t astride, uint32_t aheight, uint32_t rows_cap, uint32_t big_thr, uint32_t gang, uint32_t nbins)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t TW = 1u << TWL, CELLS = TW * FL_TILE_H;
-    constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;                           // records per lane and step
+    constexpr int ILP = TWL == 7u ? ACC_ILP : ACC_ILP_WIDE;
     static_assert(FL_PAL_W == 256, "the palette column is the record's low byte, the row the mark's");
-    using Word = uint32_t;
     // LDS: palette rows first (their gather then needs no base added), the waves' marks, the tile
     u64 *pal = reinterpret_cast<u64 *>(smem);                                                   // [rows_cap][256] palette rows in use
     uint32_t *mk = reinterpret_cast<uint32_t *>(smem + rows_cap * FL_PAL_W * 8) + (threadIdx.x >> 6) * 64;   // [64] marks of this wave
     u64 *tile = reinterpret_cast<u64 *>(smem + rows_cap * FL_PAL_W * 8 + blockDim.x * 4);       // [CELLS]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = blockDim.x >> 6;
-    // Workgroup -> (tile, part).  gang = 0: parts of a tile are consecutive workgroups.  gang = G (round 5, FLAME_BIN_GANG):
+    // Workgroup -> (tile, part).  gang = 0: parts of a tile are consecutive workgroups.  gang = G (round 5 experiment, FLAME_BIN_GANG):
     // G adjacent tiles with the SAME part are G consecutive workgroups of ONE XCD (workgroup b runs on XCD b % 8) — they start
     // together on one L2 and walk the same batches, whose sorted records put adjacent tiles' runs into the same cache lines.
     uint32_t bin, part;
@@ -220,6 +233,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #ifdef ACC_X_TIMES
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
 #endif
+
 
     // This workgroup's contiguous range of batches.  Batch id = slot * per_slot + batch_in_slot
     // (iter.hip), so the range covers a narrow range of SLOTS, and with them of palette rows (row of
@@ -249,13 +263,9 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     // (the first chunk's rows are requested before the tile is zeroed: the workgroup's first global
     // latency then runs under the zeroing instead of after it)
     u64 stagev[3];                                                 // rows_cap * 256 <= 3 * blockDim.x
-    // (an opaque copy of the thread number: the staging addresses are chunk-invariant, and hoisted out of the chunk loop they are
-    // registers held — spilled — across the record loop, which has none to spare)
-    uint32_t tid_c = tid;
-    asm volatile("" : "+v"(tid_c));
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const uint32_t i = tid_c + q * blockDim.x;
+        const uint32_t i = tid + q * blockDim.x;
         stagev[q] = i < nrows * FL_PAL_W ? palette[row_lo * FL_PAL_W + i] : 0ull;
     }
     // (so are the directory words of the wave's first group; every group then requests the next group's words
@@ -270,7 +280,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     __syncthreads();                                               // readers of the previous chunk's rows are done
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const uint32_t i = tid_c + q * blockDim.x;
+        const uint32_t i = tid + q * blockDim.x;
         if (i < nrows * FL_PAL_W) pal[i] = stagev[q];
     }
     __syncthreads();
@@ -282,7 +292,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         // slot of the group's first batch and the remainder, once per group (scalar); run r < 64 of
         // the group then belongs to slot s0 + (rem0 + r) / per_slot
         const uint32_t s0 = g0 / per_slot, rem0 = g0 - s0 * per_slot;
-        // 64 directory entries per wave; their runs form one virtual array of `total` log words
+        // 64 directory entries per wave; their runs form one virtual array of `total` records
         const uint32_t batch = g0 + lane;
 #if ACC_DIR_AHEAD
         const uint32_t e = e_next;
@@ -290,36 +300,37 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #else
         const uint32_t e = batch < ce ? drow[batch] : 0u;
 #endif
-        const uint32_t c = e & 0xffffu, first = e >> 16;                  // the run of this lane's batch: its records, its first record
+        const uint32_t c = e & 0xffffu, first = e >> 16;
         const uint32_t incl = wave_incl_scan_b(c, lane);
         const uint32_t excl = incl - c;
         const uint32_t total = __shfl(incl, 63);
-        // Which run does word v of the virtual array belong to?  Every non-empty run drops a mark at its first
+        // Which run does record v of the virtual array belong to?  Every non-empty run drops a mark at its first
         // position; a max-scan over the positions (DPP, pure VALU) then carries the latest mark to every position.
-        // This replaces a 6-step shuffle binary search + two more shuffles per word (8 trips through the LDS pipe)
-        // by one predicated LDS write, one read and one clear per step.  The mark that is exchanged is the run's LANE number (+ 1, a
-        // byte); what a word needs from its run is then fetched from that lane with ds_bpermute, computed ONCE per run by the
-        // run's directory lane:
-        //   bits 8..: 1 + (lane * batch_stride + first - excl) = 1 + (the word's index in the log, counted from the
-        //             group's first batch) - (its position v in the virtual array)
+        // This replaces a 6-step shuffle binary search + two more shuffles per record (8 trips through the LDS pipe)
+        // by one predicated LDS write, one read and one clear per 64 records.  The mark holds everything a record
+        // needs from its run, computed ONCE per run by the run's directory lane:
+        //   bits 8..: 1 + (lane * batch_records + first - excl) = 1 + (the record's index in the log, counted from
+        //             the group's first batch) - (its position v in the virtual array)
         //   bits 0-7: the run's palette row among the staged rows (a whole byte: v_perm joins it with the record's colour byte)
-        // and, for the packed log, the directory word itself (which slots of the word belong to the run).
+        // The upper field never decreases from one run to the next (first' + batch_records >= first + c: a run ends
+        // inside its batch) and is the same only where the record index is the same anyway; the row never decreases
+        // either, so the LARGEST mark at or before a position is the mark of the run the position belongs to.
         const uint32_t rslot_l = s0 + (uint32_t)(((float)(rem0 + lane) + 0.5f) * inv_ps);          // exact: small integers
         const uint32_t row_l = (uint32_t)(((float)rslot_l + 0.5f) * inv_spr) - row_lo;              // row within the staged rows
-        const uint32_t mark_l = ((lane * batch_stride + first - excl + 1u) << 8) | (row_l & 255u);
-        const unsigned char *gbase = reinterpret_cast<const unsigned char *>(log) + (size_t)g0 * batch_stride * sizeof(Word) - sizeof(Word);   // (the marks' "1 +")
+        const uint32_t mark_l = ((lane * batch_records + first - excl + 1u) << 8) | (row_l & 255u);
+        const unsigned char *gbase = reinterpret_cast<const unsigned char *>(log + (size_t)g0 * batch_records) - 4;   // (the marks' "1 +")
         uint32_t carry = 0;
-        // One step = 64 * ILP words: `fetch` finds every word's run and requests it, `process` adds its records to
-        // the tile.  The loads are issued from inline asm so that the NEXT step's requests can be in flight while
+        // One step = 64 * ILP records: `fetch` finds every record's run and requests it, `process` adds the records to
+        // the tile.  The record loads are issued from inline asm so that the NEXT step's requests can be in flight while
         // this step's records go through the palette and the tile (ACC_PIPE): the compiler would wait for them at once.
-        // A step's results are its ILP words and one register with a byte per word: the palette row, and (packed log) above it
-        // a bit per slot of the word that belongs to this tile's run.
-        static_assert(ILP >= 1 && ILP <= 4, "up to four bytes to a register");
-        auto fetch = [&](const uint32_t v0, Word (&rec)[ILP], uint32_t &rows) __attribute__((always_inline)) {
+        // A step's results are its ILP records and one word with the ILP palette rows (one byte each).
+        static_assert(ILP >= 2 && ILP <= 4, "up to four rows to a word");
+        auto fetch = [&](const uint32_t v0, uint32_t (&rec)[ILP], uint32_t &rows) __attribute__((always_inline)) {
+#if ACC_BYTE_MARKS
             // ONE exchange for the whole step: the runs that start inside it drop their lane number (+1) as a byte, every
             // lane reads its ILP positions at once, the ILP max-scans are independent instruction chains (the wait states
             // of one are filled by the others), and the marks themselves come from the runs' lanes by ds_bpermute —
-            // two waits on the LDS pipe per step instead of ILP.  (carry: the run number + 1)
+            // two waits on the LDS pipe per step instead of ILP.  (carry: the run number + 1 here, the mark below)
             unsigned char *mk8 = reinterpret_cast<unsigned char *>(mk);
             const bool starts = c != 0u && excl - v0 < 64u * ILP;
             if (starts) mk8[excl - v0] = (unsigned char)(lane + 1u);
@@ -335,69 +346,96 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
             for (int k = 0; k < ILP; ++k) {
                 mm[k] = max(mm[k], carry);
                 carry = (uint32_t)__builtin_amdgcn_readlane((int)mm[k], 63);
+                mm[k] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((mm[k] - 1u) << 2), (int)mark_l);
             }
+#endif
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
-                const uint32_t v = v0 + k * 64 + lane;
-                const uint32_t run = mm[k] - 1u;                   // the directory lane of the word's run
-                const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(run << 2), (int)mark_l);
+                const uint32_t lo = v0 + k * 64, v = lo + lane;
+#if ACC_BYTE_MARKS
+                const uint32_t m = mm[k];
+#else
+                if (c != 0u && excl - lo < 64u) mk[excl - lo] = mark_l;
+                wave_sync();                 // lanes exchange data through LDS: without it the compiler
+                uint32_t m = mk[lane];       // forwards this lane's own earlier "= 0" into the load
+                wave_sync();
+                mk[lane] = 0u;
+                m = wave_incl_maxscan(m);
+                m = max(m, carry);
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+#endif
+                // byte k of `rows` = the mark's low byte
                 rows = __builtin_amdgcn_perm(m, rows, k == 0 ? 0x03020104u : k == 1 ? 0x03020400u : k == 2 ? 0x03040100u : 0x04020100u);
-                // scalar base + 32-bit byte offset (at most 65 batch regions); positions past the end of the
-                // virtual array read the group's first word (and are not used)
-                const uint32_t voff = v < total ? ((m >> 8) + v) * (uint32_t)sizeof(Word) : (uint32_t)sizeof(Word);
+#ifdef ACC_X_NOLOG       /* timing experiments only (tools/exp_accum_parts.sh): synthesised records */
+                rec[k] = ((m * 2654435761u + v * 40503u) & ((1u << (TWL + FL_TILE_H_LOG2 + 8u)) - 1u));
+#elif 0
+                // 3-byte records: the two aligned words around the record's byte address in ONE 8-byte load (needs 4-byte
+                // alignment only), the record cut out with v_alignbyte — an unaligned 4-byte load measured +31 %
+                rec[k] = 0u;
+                if (v < total) {
+                    const size_t ba = ((size_t)g0 * batch_records + (v + (m >> 8) - 1u)) * 3u;
+                    struct __attribute__((packed, aligned(4))) W2 { uint32_t lo, hi; };
+                    const W2 w = *reinterpret_cast<const W2 *>(reinterpret_cast<const unsigned char *>(log) + (ba & ~(size_t)3));
+                    rec[k] = __builtin_amdgcn_alignbyte(w.hi, w.lo, (uint32_t)ba & 3u) & 0xffffffu;
+                }
+#else
+                // scalar base + 32-bit byte offset (at most 4 * 65 * batch_records); positions past the end of the
+                // virtual array read the group's first record (and are not used)
+                const uint32_t voff = v < total ? ((m >> 8) + v) << 2 : 4u;
                 asm volatile("global_load_dword %0, %1, %2" ACC_LOAD_MOD : "=v"(rec[k]) : "v"(voff), "s"(gbase) : "memory");
+#endif
             }
         };
-        auto process = [&](const uint32_t v0, Word (&rec)[ILP], const uint32_t rows) __attribute__((always_inline)) {
-            constexpr int NR = ILP;
-            constexpr int k0 = 0;
-            {
-            bool live[NR];
-            uint32_t r[NR];                                        // {row in tile | column | palette column}
-            u64 val[NR];
-#pragma unroll
-            for (int k = 0; k < ILP; ++k) { r[k] = rec[k]; live[k] = v0 + k * 64 + lane < total; }
-            auto gather = [&](const int i) __attribute__((always_inline)) {
-                val[i] = pal[__builtin_amdgcn_perm(rows, r[i], 0x0c0c0000u | ((4u + k0 + i) << 8))];      // (row << 8) | colour byte: FL_PAL_W == 256
+        auto process = [&](const uint32_t v0, uint32_t (&rec)[ILP], const uint32_t rows) __attribute__((always_inline)) {
+            bool live[ILP];
+            u64 val[ILP];
+            auto gather = [&](const int k) __attribute__((always_inline)) {
+#ifdef ACC_X_NOPAL
+                val[k] = (1ull << 54) | (rows & 0xffu) | (rec[k] & 0xffu);
+#else
+                val[k] = pal[__builtin_amdgcn_perm(rows, rec[k], 0x0c0c0000u | ((4u + k) << 8))];      // (row << 8) | colour byte: FL_PAL_W == 256
+#endif
             };
 #pragma unroll
-            for (int i = 0; i < NR; ++i)
-                if (i < ACC_GATHER_AHEAD) gather(i);
+            for (int k = 0; k < ILP; ++k) {
+                live[k] = v0 + k * 64 + lane < total;
+                if (k < ACC_GATHER_AHEAD) gather(k);
+            }
             // A cell that takes most of the samples (a point attractor takes all of them) would receive
             // thousands of adds between the moment its count passes the drain threshold and the moment
             // the drain executes — enough to carry out of the 10-bit count.  When at least 48 lanes of the
-            // group's first 64 records share one cell, the group is examined record set by record set:
-            // the lanes that share the first live lane's cell are summed in registers (at most 64 hits: no
-            // field overflows) and go straight to the float accumulator (hot_group; the
-            // test on the first set costs a handful of instructions per group).
+            // step's first 64 records share one cell, the step is examined record set by record set:
+            // the lanes that share the first lane's cell are summed in registers (at most 64 hits: no
+            // field overflows) and go straight to the float accumulator (hot_group, out of line; the
+            // test on the first set costs four instructions per 256 records).
             {
-                const uint32_t o0 = r[0] >> 8;
-                const unsigned long long lv0 = __ballot(live[0]);
-                const uint32_t o00 = (uint32_t)__builtin_amdgcn_readlane((int)o0, lv0 ? (int)__builtin_ctzll(lv0) : 0);      // the first live lane's cell
-                if (__builtin_expect(__popcll(__ballot(live[0] && o0 == o00)) >= 48, 0)) {
+                const uint32_t o0 = rec[0] >> 8;
+                if (__builtin_expect(__popcll(__ballot(live[0] && o0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)o0))) >= 48, 0)) {
 #pragma unroll
-                    for (int i = ACC_GATHER_AHEAD; i < NR; ++i) gather(i);          // (the rare path looks at every record's entry)
+                    for (int k = ACC_GATHER_AHEAD; k < ILP; ++k) gather(k);          // (the rare path looks at every record's entry)
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        const uint32_t off = r[i] >> 8;
-                        const unsigned long long lv = __ballot(live[i]);
-                        if (lv == 0ull) continue;
-                        const uint32_t off0 = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)__builtin_ctzll(lv));
-                        const bool mine = live[i] && off == off0;
+                    for (int k = 0; k < ILP; ++k) {
+                        const uint32_t off = rec[k] >> 8;
+                        const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                        const bool mine = live[k] && off == off0;
                         const unsigned long long grp = __ballot(mine);
                         if (__popcll(grp) >= 16) {
-                            hot_group(mine ? val[i] : 0ull, grp, (ty * FL_TILE_H + (off0 >> TWL)) * astride + tx * TW + (off0 & (TW - 1u)), out4);
-                            live[i] = live[i] && !mine;
+                            hot_group(mine ? val[k] : 0ull, grp, (ty * FL_TILE_H + (off0 >> TWL)) * astride + tx * TW + (off0 & (TW - 1u)), out4);
+                            live[k] = live[k] && !mine;
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const uint32_t off = r[i] >> 8;                                  // (ly << TWL) | lx
-                if (i + ACC_GATHER_AHEAD < NR) gather(i + ACC_GATHER_AHEAD);           // palette entries are requested ACC_GATHER_AHEAD records ahead of their add
-                if (!live[i]) continue;
-                const u64 old = __hip_atomic_fetch_add(tile + off, val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < ILP; ++k) {
+                const uint32_t off = rec[k] >> 8;                                // (ly << TWL) | lx
+                if (k + ACC_GATHER_AHEAD < ILP) gather(k + ACC_GATHER_AHEAD);           // palette entries are requested ACC_GATHER_AHEAD records ahead of their add
+                if (!live[k]) continue;
+#ifdef ACC_X_NOATOM
+                const u64 old = tile[off ^ 1u]; if (val[k] == 0x1234567ull) tile[off] = old;
+#else
+                const u64 old = __hip_atomic_fetch_add(tile + off, val[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 if ((uint32_t)(old >> 32) >= (128u << 23)) {                     // 256 hits: drained early, three quarters of the count's range left for adds in flight
                     const u64 cur = __hip_atomic_exchange(tile + off, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if ((uint32_t)(cur >> 32) != 0u) {
@@ -406,22 +444,19 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
                     }
                 }
             }
-            }
         };
-        // the wait names the words it is for: nothing of `process` can be scheduled above it
+        // the wait names the records it is for: nothing of `process` can be scheduled above it
 #define ACC_WAIT(n, r) do { if constexpr (ILP == 4) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[ILP - 2]), "+v"(r[ILP - 1]) :: "memory"); \
                             else if constexpr (ILP == 3) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[ILP - 1]) :: "memory"); \
-                            else if constexpr (ILP == 2) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[ILP - 1]) :: "memory"); \
-                            else asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]) :: "memory"); } while (0)
-#define ACC_WAIT_NEWER(r) do { if constexpr (ILP == 4) ACC_WAIT(4, r); else if constexpr (ILP == 3) ACC_WAIT(3, r); else if constexpr (ILP == 2) ACC_WAIT(2, r); else ACC_WAIT(1, r); } while (0)       /* all but the ILP newest loads */
+                            else asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]) :: "memory"); } while (0)
+#define ACC_WAIT_NEWER(r) do { if constexpr (ILP == 4) ACC_WAIT(4, r); else if constexpr (ILP == 3) ACC_WAIT(3, r); else ACC_WAIT(2, r); } while (0)       /* all but the ILP newest loads */
         constexpr uint32_t STEP = 64 * ILP;
-#if ACC_PIPE
+#if ACC_PIPE && !defined(ACC_X_NOLOG)
         // Two sets of results alternate (A, B): while one set's records are added, the other's are on their way.  Each
         // set has ONE place where it is requested, and B's processing trails into the next iteration: a second place
         // (a prologue, say) would make the compiler merge two definitions, i.e. copy registers whose loads are still
         // in flight (tools/check_asm_atomics.py looks for exactly that in the assembly).
-        Word recA[ILP] = {}, recB[ILP] = {};
-        uint32_t rowsA = 0u, rowsB = 0u;
+        uint32_t recA[ILP] = {}, recB[ILP] = {}, rowsA = 0u, rowsB = 0u;
 #ifdef ACC_X_TIMES
 #define ACC_T(sum) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime(); sum += t_ - x_t; x_t = t_; } while (0)
         uint32_t x_t = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -430,9 +465,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 #endif
         for (uint32_t v0 = 0; v0 < total; v0 += 2 * STEP) {
             ACC_T(x_other); fetch(v0, recA, rowsA); ACC_T(x_fetch);
-            // B is older than A: A stays in flight.  (The wait is executed in the first iteration too, where it is satisfied at once: no path
-            // reaches B's next request with a load of B in flight.)
-            ACC_WAIT_NEWER(recB); if (v0 != 0u) { ACC_T(x_wait); process(v0 - STEP, recB, rowsB); ACC_T(x_proc); }
+            // (the marker tells tools/check_asm_atomics.py that the branch around this block is the first step's: nothing of B in flight)
+            if (v0 != 0u) { asm volatile("; acc-guarded-block"); ACC_WAIT_NEWER(recB); ACC_T(x_wait); process(v0 - STEP, recB, rowsB); ACC_T(x_proc); }       // B is older than A: A stays in flight
             if (v0 + STEP < total) { fetch(v0 + STEP, recB, rowsB); ACC_T(x_fetch); ACC_WAIT_NEWER(recA); } else ACC_WAIT(0, recA);
             ACC_T(x_wait); process(v0, recA, rowsA); ACC_T(x_proc);
 #ifdef ACC_X_TIMES
@@ -445,10 +479,11 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
         }
 #else
         for (uint32_t v0 = 0; v0 < total; v0 += STEP) {
-            Word rec[ILP];
-            uint32_t rows = 0u;
+            uint32_t rec[ILP], rows = 0u;
             fetch(v0, rec, rows);
+#if !defined(ACC_X_NOLOG)
             ACC_WAIT(0, rec);
+#endif
             process(v0, rec, rows);
         }
 #endif
@@ -460,7 +495,8 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     }
     __syncthreads();
 
-    // add the tile to the global packed accumulator
+    // add the tile to the global packed accumulator: one row segment of 64 cells per wave
+    // instruction (coalesced atomics), draining cells that reach 512 hits
 #ifdef ACC_X_TIMES
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) {
         unsigned long long *o = acc_wg_steps[blockIdx.x];
@@ -469,7 +505,51 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
     __syncthreads();
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    add_tile_to_cells<TWL>(tile, atom, out4, tx, ty, astride, aheight, big_thr);
+#ifndef ACC_NO_DRAIN     /* timing experiment only: tools/exp_drain.sh */
+    // ACC_ADD_ILP returning atomics per thread are in flight before the first result is looked at (one at a time,
+    // the loop was eight serial round trips to L2: 6.5 us of a 43 us workgroup)
+    for (uint32_t i0 = tid; i0 < CELLS; i0 += blockDim.x * ACC_ADD_ILP) {
+        u64 old[ACC_ADD_ILP];
+        uint32_t big = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < ACC_ADD_ILP; ++k) {
+            const uint32_t i = i0 + k * blockDim.x;
+            old[k] = 0ull;
+            if (i < CELLS) {
+                const u64 v = tile[i];
+                const uint32_t px = tx * TW + (i & (TW - 1u)), py = ty * FL_TILE_H + (i >> TWL);
+                if (v != 0ull && px < astride && py < aheight) {
+                    // A packed add must never carry the 10-bit count past 1023.  Each cell receives at
+                    // most `nparts` adds per launch (one per workgroup of its tile) onto a flushed cell,
+                    // so chunks below big_thr = 1024/nparts hits are safe; larger ones go straight to the floats.
+                    // (Round 4's FLAME_FLUSH_LAST — one flush per frame instead of one per launch, for the on-die log experiment —
+                    // sized this threshold for a drain at 256 hits while cells drain at 512 (`full` below): removed in round 5.)
+                    if ((uint32_t)(v >> 54) >= big_thr) big |= 1u << k;
+                    else                                         // (as asm: the compiler waits for every returning atomic at the end of its branch)
+                        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "+v"(old[k]) : "v"(atom + py * astride + px), "v"(v) : "memory");
+                }
+            }
+        }
+        static_assert(ACC_ADD_ILP == 8 || ACC_ADD_ILP == 4, "the wait below names every result");
+        if constexpr (ACC_ADD_ILP == 8)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]) :: "memory");
+#pragma unroll
+        for (uint32_t k = 0; k < ACC_ADD_ILP; ++k) {
+            const bool full = (uint32_t)(old[k] >> 32) >= (256u << 23);
+            if (full || ((big >> k) & 1u)) {                      // rare: the cell is looked up again
+                const uint32_t i = i0 + k * blockDim.x;
+                const uint32_t gi = (ty * FL_TILE_H + (i >> TWL)) * astride + tx * TW + (i & (TW - 1u));
+                if (full) {
+                    const u64 cur = __hip_atomic_exchange(atom + gi, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(cur >> 32) != 0u) spill_cell(cur, gi, out4);
+                } else
+                    spill_cell(tile[i], gi, out4);
+            }
+        }
+    }
+#endif
 #ifdef ACC_X_TIMES
     __syncthreads();
     if (tid == 0 && blockIdx.x < ACC_X_MAXWG) acc_wg_times[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
@@ -488,6 +568,7 @@ k_accum_tiles(const uint32_t *__restrict__ log, const uint32_t *__restrict__ dir
 //    one v_bfe_i32 + one v_and per slot, no exec mask, no branch) — and adds nothing;
 //  * the LDS layout is fixed at compile time and addressed by number, so that palette and tile bases are immediate offsets of the
 //    LDS instructions, and palette column and cell offset go from the 64-bit word to their addresses in one shift + one mask each.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u64 lds_u64_t;
 typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 __device__ __forceinline__ lds_u64_t *lds64(uint32_t byte) { return (lds_u64_t *)(uintptr_t)byte; }
@@ -629,7 +710,7 @@ k_accum_tiles_p3(const uint32_t *__restrict__ log, const uint32_t *__restrict__ 
                     const bool mine = live && cell8[j] >> 3 == off0;
                     const unsigned long long grp = __ballot(mine);
                     if (__popcll(grp) >= 16) {
-                        hot_group(mine ? val[j] : 0ull, grp, (ty * FL_TILE_H + (off0 >> TWL)) * astride + tx * TW + (off0 & (TW - 1u)), out4);
+                        hot_group_sw(mine ? val[j] : 0ull, grp, (ty * FL_TILE_H + (off0 >> TWL)) * astride + tx * TW + (off0 & (TW - 1u)), out4);
                         if (mine) val[j] = 0ull;
                     }
                 }

@@ -33,6 +33,8 @@ def regs_of(t):
 
 
 def parse(t):
+    if t.startswith('; acc-guarded-block'):
+        return ('marker', None, None, t, None)
     if t.startswith('s_waitcnt') and 'vmcnt(0)' in t:
         return ('wait0', None, None, t, None)
     mw = WAITN.match(t)
@@ -72,7 +74,17 @@ def check_function(name, body):
                     atoms, loads = set(c[0]), list(c[1])      # (the state with more in flight: the stricter one)
                 fresh = False
                 continue
-            if kind in ('reset', 'cjump') and target in where and where[target] > k:
+            # A conditional branch around a block that the source marks as guarded ("if this is not the group's first step: wait for the
+            # older set, add it") is the first step's path, taken only when nothing of that set is in flight: its state is not carried.
+            guarded = False
+            if kind == 'cjump' and target in where and where[target] > k:
+                for j in range(k + 1, where[target]):
+                    if ins[j][0] in ('load', 'atom', 'label', 'waitn', 'wait0'):
+                        break
+                    if ins[j][0] == 'marker':
+                        guarded = True
+                        break
+            if kind in ('reset', 'cjump') and not guarded and target in where and where[target] > k:
                 c = carried.get(target)
                 if c is None or len(c[0]) + len(c[1]) < len(atoms) + len(loads):
                     carried[target] = (set(atoms), list(loads))
@@ -99,6 +111,8 @@ def check_function(name, body):
                 # a loop's back-edge: once more over the body with what is in flight now
                 if not second and target in where and where[target] < k and (atoms or loads):
                     walk(where[target], k, atoms, loads, True)
+            elif kind == 'marker':
+                pass
             elif kind == 'op':
                 inflight = {r for a in atoms for r in a} | {r for l in loads for r in l}
                 hit = regs & inflight
@@ -120,6 +134,9 @@ for ln in lines:
         name, cur = m.group(1), []
         continue
     t = ln.strip()
+    if name is not None and t.startswith('; acc-guarded-block'):
+        cur.append(t)              # (a marker the kernel source leaves in front of a guarded block, see parse)
+        continue
     if name is None or not t or t.startswith(';') or (t.startswith('.') and not LABEL.match(t)):
         continue
     cur.append(t)
