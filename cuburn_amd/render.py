@@ -99,7 +99,7 @@ class Framebuffers(object):
     # stream lane's kernels run beside it.  With more samples the second launch costs more than the fuse saves
     # (profiles/r03_slots_by_samples.txt).  Decided per frame from its sample count (set_dim).
     NARROW_FEW = (4, 1024)
-    # The same for the 8-wave geometry (round 5): 512 slots whose two halves of four waves walk two temporal samples — the
+    # The same for the 8-wave geometry (round 5; since round 6 only through FLAME_NW=8 FLAME_NSLOTS=512): 512 slots whose two halves of four waves walk two temporal samples — the
     # reference's 1024 samples x 256 threads exactly, bit for bit the walkers of NARROW_FEW, sharing 8192-record sort batches
     # (csrc/iter.hip "Sub-blocks of four waves").  1024 slots of 8 waves walk 512 threads per sample: twice the un-plotted rounds.
     WIDE_FEW = (8, 512)
@@ -185,8 +185,11 @@ class Framebuffers(object):
                     want = self._cfg
             elif want == self.WIDE:
                 if nsamples is not None:
-                    want = self.WIDE_FEW if nsamples <= self.FEW_SAMPLES else self.WIDE
-                elif self._cfg in (self.WIDE, self.WIDE_FEW):
+                    # (round 6: frames of few samples take the 16-wave quarters from ~1440p up already — batches of 16384 records
+                    # instead of 8192 give the 4K accumulate runs of 15 records: cfg4 2.94-2.99 -> 2.77-2.83 ms per frame,
+                    # profiles/r06_experiments.txt section 10; the paired 8-wave geometry stays available to an explicit FLAME_NW=8)
+                    want = self.HUGE_FEW if nsamples <= self.FEW_SAMPLES else self.WIDE
+                elif self._cfg in (self.WIDE, self.WIDE_FEW, self.HUGE_FEW):
                     want = self._cfg
             elif want == self.HUGE:
                 if nsamples is not None:

@@ -173,11 +173,12 @@ def test_cfg4_full_size_animation_frame(built):
         outs.append(np.array(h_out))
     assert outs[0].shape == (2160, 3840, 4) and outs[0][..., 3].max() > 100
     assert np.abs(outs[0].astype(np.int32) - outs[1].astype(np.int32)).mean() > 0.05
-    # queue_frame knows the frame's sample count: 2^28 samples take the paired 8-wave geometry (512 workgroups, the reference's
-    # 1024 temporal samples x 256 walkers), and the frame it renders is the frame the 1024-slot geometry above rendered
-    assert (m.fb.nw, m.fb.nslots, m.fb.ntemporal) == (8, 512, 1024)
+    # queue_frame knows the frame's sample count: 2^28 samples take 16-wave workgroups in quarters (round 6: 256 workgroups, the
+    # reference's 1024 temporal samples x 256 walkers, sort batches of 16384 records), and the frame it renders is the frame the
+    # 1024-slot geometry above rendered
+    assert (m.fb.nw, m.fb.nslots, m.fb.ntemporal) == (16, 256, 1024)
     rdr2, gprof2, dim2, td2, nrun2, front2 = iterate_frame(m, gnm, prof, tc, 2 ** 28)
-    assert (m.fb.nw, m.fb.nslots) == (8, 512) and nrun2 == nrun
+    assert (m.fb.nw, m.fb.nslots) == (16, 256) and nrun2 == nrun
     check_against_cpu_game(gnm, prof, tc, m.fb.ntemporal, dim2, front2, nrun2, 2 ** 27, 32, 0.02, 2e-3, 1.5 / 255)
     d1, d2 = front[:, 3].astype(np.float64), front2[:, 3].astype(np.float64)
     assert abs(d1.sum() - d2.sum()) < 2e-3 * d1.sum()
