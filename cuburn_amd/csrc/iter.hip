@@ -43,6 +43,19 @@
 #ifndef FL_LOG_NT
 #define FL_LOG_NT 1          /* the sample log leaves with non-temporal stores: written once, read by k_accum_tiles much later (k_accum_tiles 380 -> 347 us, k_iter unchanged) */
 #endif
+#ifndef FL_ITER_MERGE_MAX_XF
+#define FL_ITER_MERGE_MAX_XF 4 /* per-genome binned kernels of at most this many xforms run a round's plot inside the NEXT round's xform block
+                                  (same results; 0: never.  cfg2, 3 xforms: k_iter_spec 653 -> 627 us; 8 xforms + final: -0.3 ... -1.2 %) */
+#endif
+#ifndef FL_SORT_FULL_COPY
+#define FL_SORT_FULL_COPY 1
+#endif
+#ifndef FL_SORT_LOCAL_TID
+#define FL_SORT_LOCAL_TID 1
+#endif
+#ifndef FL_SCATTER_DEPTH
+#define FL_SCATTER_DEPTH 4     /* returning cursor adds a thread keeps in flight in the scatter */
+#endif
 #ifndef FL_ITER_ROT3
 #define FL_ITER_ROT3 1
 #endif
@@ -190,10 +203,11 @@ struct XfVec { float xo, yo, cprod, pxo, pyo; };
 // NEXT round's xform (chosen a round ahead) behind the swap: one address instruction and one ds_read_b128 per round instead of the two v_mov of
 // the affine and the v_sub + v_mov + v_mul of the colour blend.
 constexpr bool kTab = !kSpecResident && FL_HOIST_BUDGET >= 12 && FL_SPEC_NXF * 16 <= FL_XTAB_BYTES;
-template <int I>
+template <int I, class Extra>
 __device__ __forceinline__ void spec_apply_xf_tab(const XfHead &h, const float4 &t, const float *__restrict__ xf,
-                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl, Extra &&extra)
 {
+    extra();          // (the previous round's plot, in the xform's own block: two independent chains for the scheduler; see iter_body)
     float tx = fmaf(h.f[0], x, fmaf(h.f[1], y, t.x));
     float ty = fmaf(h.f[3], x, fmaf(h.f[4], y, t.y));
     float ox = -0.0f, oy = -0.0f;
@@ -207,15 +221,15 @@ __device__ __forceinline__ void spec_apply_xf_tab(const XfHead &h, const float4 
     asm volatile("" : "+v"(c));
     x = ox; y = oy;
 }
-template <int LO, int HI>
+template <int LO, int HI, class Extra>
 __device__ __forceinline__ void spec_dispatch_tab(int k, const XfHead &h, const float4 &t, const float *__restrict__ xf,
-                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl = nullptr)
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail *tl, Extra &&extra)
 {
-    if constexpr (HI - LO == 1) spec_apply_xf_tab<LO>(h, t, xf, x, y, c, r, tl);
+    if constexpr (HI - LO == 1) spec_apply_xf_tab<LO>(h, t, xf, x, y, c, r, tl, extra);
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch_tab<LO, MID>(k, h, t, xf, x, y, c, r, tl);
-        else spec_dispatch_tab<MID, HI>(k, h, t, xf, x, y, c, r, tl);
+        if (k < MID) spec_dispatch_tab<LO, MID>(k, h, t, xf, x, y, c, r, tl, extra);
+        else spec_dispatch_tab<MID, HI>(k, h, t, xf, x, y, c, r, tl, extra);
     }
 }
 // The final xform's record is constant for the slot as well: its operands are held the same way (three registers, five with a post affine).
@@ -238,28 +252,28 @@ __device__ __forceinline__ void spec_apply_xf_res(const XfHead &h, const XfVec &
     else { const float csp = h.f[13]; c = fmaf(c, 1.0f - csp, h.f[12] * csp); }
     x = ox; y = oy;
 }
-template <int LO, int HI>
+template <int LO, int HI, class Extra>
 __device__ __forceinline__ void spec_dispatch_res(int k, const XfHead (&heads)[FL_SPEC_NXF], const XfVec (&hv)[FL_SPEC_NXF], const float *__restrict__ xf0, int xf_stride,
-                                                  float &x, float &y, float &c, mwc_t &r, const XfTail (&tails)[FL_SPEC_NXF])
+                                                  float &x, float &y, float &c, mwc_t &r, const XfTail (&tails)[FL_SPEC_NXF], Extra &&extra)
 {
-    if constexpr (HI - LO == 1) spec_apply_xf_res<LO>(heads[LO], hv[LO], xf0 + LO * xf_stride, x, y, c, r, FL_EARLY_TAIL ? &tails[LO] : nullptr);
+    if constexpr (HI - LO == 1) { extra(); spec_apply_xf_res<LO>(heads[LO], hv[LO], xf0 + LO * xf_stride, x, y, c, r, FL_EARLY_TAIL ? &tails[LO] : nullptr); }
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails);
-        else spec_dispatch_res<MID, HI>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails);
+        if (k < MID) spec_dispatch_res<LO, MID>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails, extra);
+        else spec_dispatch_res<MID, HI>(k, heads, hv, xf0, xf_stride, x, y, c, r, tails, extra);
     }
 }
 
 // wave-uniform dispatch over the selectable xforms [LO, HI): a binary tree of scalar compares
-template <int LO, int HI>
+template <int LO, int HI, class Extra>
 __device__ __forceinline__ void spec_dispatch(int k, const XfHead &h, const float *__restrict__ xf,
-                                              float &x, float &y, float &c, mwc_t &r)
+                                              float &x, float &y, float &c, mwc_t &r, Extra &&extra)
 {
-    if constexpr (HI - LO == 1) spec_apply_xf<LO>(h, xf, x, y, c, r);
+    if constexpr (HI - LO == 1) { extra(); spec_apply_xf<LO>(h, xf, x, y, c, r); }
     else {
         constexpr int MID = (LO + HI) / 2;
-        if (k < MID) spec_dispatch<LO, MID>(k, h, xf, x, y, c, r);
-        else spec_dispatch<MID, HI>(k, h, xf, x, y, c, r);
+        if (k < MID) spec_dispatch<LO, MID>(k, h, xf, x, y, c, r, extra);
+        else spec_dispatch<MID, HI>(k, h, xf, x, y, c, r, extra);
     }
 }
 #endif
@@ -509,7 +523,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 
     // One round of the walk: reseed bad points, apply the chosen xform, swap walkers between waves.
     uint32_t par = 0;                                   // parity of the round: which of the two swap buffers
-    auto advance = [&](const uint32_t dst) __attribute__((always_inline)) {
+    auto advance = [&](const uint32_t dst, auto &&extra) __attribute__((always_inline)) {
         // Wave priority: the walk — everything up to the swap's barrier and the reads behind it — runs at a raised
         // priority, the plotting that follows at the normal one.  A SIMD holds one wave of each of six workgroups; the
         // wave whose three siblings (on the other SIMDs) already wait at the round's barrier should not queue behind
@@ -534,12 +548,12 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         // on this kernel's critical path) and still has the swap, the barrier and the rest of the round to
         // arrive: k_iter 0.717 -> 0.70 ms, the interpreter kernel -15 %.
 #ifdef FL_RTC
-        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx, tails);
-        else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx, FL_EARLY_TAIL ? &tail : nullptr);
-        else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx);
+        if constexpr (RESIDENT) spec_dispatch_res<0, FL_SPEC_NXF>(k_cur, heads, hv, P + xf_off, xf_stride, x, y, color, rctx, tails, extra);
+        else if constexpr (SPEC && kTab) spec_dispatch_tab<0, FL_SPEC_NXF>(k_cur, hnext, tcur, xf_cur, x, y, color, rctx, FL_EARLY_TAIL ? &tail : nullptr, extra);
+        else if constexpr (SPEC) spec_dispatch<0, FL_SPEC_NXF>(k_cur, hnext, xf_cur, x, y, color, rctx, extra);
         else
 #endif
-        apply_xf(hnext, xf_cur, var_stride, x, y, color, rctx);
+        { extra(); apply_xf(hnext, xf_cur, var_stride, x, y, color, rctx); }
         if constexpr (!RESIDENT) hnext = load_head(xf_next);
 #ifdef FL_RTC
         if constexpr (SPEC && kTab && FL_EARLY_TAIL) {
@@ -605,16 +619,13 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             for (uint32_t i = from; i < to; ++i) body(next_dst(), i);
         }
     };
-    if (SPLIT_FUSE) rounds(0u, nfuse, [&](uint32_t dst, uint32_t) __attribute__((always_inline)) { advance(dst); });
-    uint32_t fuse_left = SPLIT_FUSE ? 0u : nfuse;
-    for (uint32_t rd = SPLIT_FUSE ? nfuse : 0u; rd < nrounds;) {
-    const uint32_t blen = fuse_left ? fuse_left : BINNED ? min(bg.rounds, nrounds - rd) : nrounds - rd;
-    const bool plotting = fuse_left == 0u;
-    fuse_left = 0u;
-    rounds(0u, blen, [&](const uint32_t dst, const uint32_t staged) __attribute__((always_inline)) {
-        advance(dst);
-        if (!SPLIT_FUSE && !plotting) return;
-
+#ifdef FL_RTC
+    constexpr bool MERGE = BINNED && SPEC && SPLIT_FUSE && FL_SPEC_NXF <= FL_ITER_MERGE_MAX_XF;
+#else
+    constexpr bool MERGE = false;
+#endif
+    // The plot of a round, in two parts: the final xform (which may draw random numbers) ...
+    auto plot_head = [&](float &cx, float &cy, float &cf) __attribute__((always_inline)) {
         float fx = x, fy = y, fc = color;
 #ifdef FL_RTC
         if constexpr (SPEC) {
@@ -623,8 +634,16 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
         } else
 #endif
         if (has_final) { const XfHead hfin = load_head(xf_final); apply_xf(hfin, xf_final, var_stride, fx, fy, fc, rctx); }   // iter.py:302-307
-        const float cx = fmaf(cam0, fx, fmaf(cam1, fy, cam2));              // iter.py:306-309
-        const float cy = fmaf(cam3, fx, fmaf(cam4, fy, cam5));
+        // the camera and the colour's scale here too: the point's registers are free before the next round's reseed can
+        // write them (kept for the second part, the MERGE loop below paid three register copies per round)
+        cx = fmaf(cam0, fx, fmaf(cam1, fy, cam2));                          // iter.py:306-309
+        cy = fmaf(cam3, fx, fmaf(cam4, fy, cam5));
+        // iter.py:346-348; rint of a value in [0, 255] = the low mantissa bits of (value + 2^23): the float adder rounds to nearest even
+        cf = fminf(fmaxf(fmaf(fc, 255.0f, color_dither), 0.0f), 255.0f) + 8388608.0f;
+        if constexpr (MERGE) asm volatile("" : "+v"(cx), "+v"(cy), "+v"(cf));      // (here, not sunk behind the reseed)
+    };
+    // ... and the cell and the record or the add (no random numbers in the binned back-end)
+    auto plot_rest = [&](const float cx, const float cy, const float cf, const uint32_t staged) __attribute__((always_inline)) {
         // iter.py:313-317: round to nearest even, reject outside [0, astride) x [0, aheight).
         // Adding 1.5 * 2^23 rounds to the nearest integer (ties to even) in the float adder and leaves
         // that integer in the low mantissa bits: for every finite or non-finite cx the difference
@@ -646,9 +665,7 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 if (mwc_next_01(rctx) > frcp(mult)) { ok = false; if (COUNT) ++n_drop; }
             }
         }
-        const float cf = fmaf(fc, 255.0f, color_dither);                    // iter.py:346-348
-        // rint of a value in [0, 255] = the low mantissa bits of (value + 2^23): the float adder rounds to nearest even
-        const uint32_t cbits = __float_as_uint(fminf(fmaxf(cf, 0.0f), 255.0f) + 8388608.0f);
+        const uint32_t cbits = __float_as_uint(cf);
         const int ci = (int)((cbits - 0x4b000000u) & 0xffu);
         const u64 val = BINNED ? 0ull : palrow[ci];                         // iter.py:351
 
@@ -673,17 +690,61 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
             const uint32_t rec = __builtin_amdgcn_perm(t2, cbits, 0x06050400u);
             if (WIDE) skey[staged * NT + tid] = (uint16_t)bin;
             stage[staged * NT + tid] = rec;
+#ifndef FL_X_NO_CNT         /* timing experiment (wrong results): no count per record */
             __hip_atomic_fetch_add(my_cnt + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         } else {
             // measurement mode: everything but the accumulate (ceiling of the walk itself)
             pend_old += ok ? val + gi : 0ull;
         }
         if (COUNT) n_acc += ok;
+    };
+    auto no_extra = []() __attribute__((always_inline)) {};
+    // MERGE: the walk of round k + 1 does not depend on the plot of round k past its final xform — the camera, the
+    // cell, the record, the count.  Placed in the chosen xform's own block that work gives the scheduler a second,
+    // independent chain to fill the first one's latencies with (the kernel waits on dependent issue at four waves per
+    // SIMD, not on throughput).  Same order of everything a lane draws and writes: A1 P1 A2 P2 ... An Pn.
+    if (SPLIT_FUSE) rounds(0u, MERGE && nfuse < nrounds ? nfuse + 1u : nfuse, [&](uint32_t dst, uint32_t) __attribute__((always_inline)) { advance(dst, no_extra); });
+    uint32_t fuse_left = SPLIT_FUSE ? 0u : nfuse;
+    for (uint32_t rd = SPLIT_FUSE ? nfuse : 0u; rd < nrounds;) {
+    const uint32_t blen = fuse_left ? fuse_left : BINNED ? min(bg.rounds, nrounds - rd) : nrounds - rd;
+    const bool plotting = fuse_left == 0u;
+    fuse_left = 0u;
+    if constexpr (MERGE) {
+        // the walk of this batch's first round has run; its last round's walk belongs to the next batch
+        const uint32_t last = rd + blen >= nrounds ? 1u : 0u;
+        rounds(0u, blen - last, [&](const uint32_t dst, const uint32_t staged) __attribute__((always_inline)) {
+            float fx, fy, fc;
+            plot_head(fx, fy, fc);          // (camera-space x, y and the scaled colour)
+            advance(dst, [&]() __attribute__((always_inline)) { plot_rest(fx, fy, fc, staged); });
+        });
+        if (last) { float fx, fy, fc; plot_head(fx, fy, fc); plot_rest(fx, fy, fc, blen - 1u); }
+    } else
+    rounds(0u, blen, [&](const uint32_t dst, const uint32_t staged) __attribute__((always_inline)) {
+        advance(dst, no_extra);
+        if (!SPLIT_FUSE && !plotting) return;
+        float fx, fy, fc;
+        plot_head(fx, fy, fc);
+        plot_rest(fx, fy, fc, staged);
     });
     rd += blen;
+#ifdef FL_X_SKIP_SORT      /* timing experiment (wrong results): no batch epilogue at all */
+    if (false) {
+#else
     if (BINNED && plotting) {
-            {
-                const uint32_t staged = blen;
+#endif
+            // The batch epilogue, compiled twice: for the full batch — every "is there a record" test folds away and the scatter
+            // is straight-line code — and for a launch's short last batch.
+            auto sort_batch = [&](const uint32_t staged) __attribute__((always_inline)) {
+#if FL_SORT_LOCAL_TID
+                // The thread number behind an empty asm: the addresses the epilogue derives from it are then computed here, once
+                // per batch, instead of being held in ~15 registers across the whole kernel (the compiler hoists them as
+                // loop invariants; the epilogue is where the register count peaks).
+                uint32_t tid_local = threadIdx.x;
+                asm volatile("" : "+v"(tid_local));
+                const uint32_t tid = tid_local, l = tid & 63u;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+#endif
                 // slot-major: the batches of a slot are neighbours in the log and the directory, so a range
                 // of batch ids covers few slots, i.e. few palette rows (binned.hip stages them in LDS)
                 const uint32_t batch_id = slot * (bg.nbatch_total / gridDim.x) + batch_in_slot;
@@ -704,7 +765,10 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 // wave walking all 2109 tiles of an 8K image kept the other fifteen waiting for 15 %
                 // of the kernel.)
                 const uint32_t nchunk = (bg.nbins + 64u) >> 6;          // tiles 0..nbins, the last one = "no record"
-                if (nchunk <= FL_SCAN_SERIAL_MAX) { // few tiles (1080p: 5 chunks): one wave is quicker than a second barrier
+#ifdef FL_X_NO_SCAN         /* timing experiment (wrong results) */
+                if (true) { if (tid == 0) *s_nvalid = staged * NT; } else
+#endif
+                if (nchunk <= FL_SCAN_SERIAL_MAX) { // few tiles (1080p: 4 chunks): one wave is quicker than a second barrier
                     if (w == 0) {
                         uint32_t running = 0;
                         for (uint32_t c0 = 0; c0 <= bg.nbins; c0 += 64) {
@@ -760,20 +824,34 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 __syncthreads();
                 // scatter, four records per thread in flight (the returning LDS atomic is a
                 // ~100-cycle round trip; one at a time this loop was a quarter of the kernel)
+#ifndef FL_X_NO_SCATTER     /* timing experiment (wrong results) */
 #pragma unroll
-                for (int q0 = 0; q0 < FL_BIN_R_MAX; q0 += 4) {
+                for (int q0 = 0; q0 < FL_BIN_R_MAX; q0 += FL_SCATTER_DEPTH) {
                     if ((uint32_t)q0 >= staged) break;
-                    uint32_t pos[4];
+                    uint32_t pos[FL_SCATTER_DEPTH];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < FL_SCATTER_DEPTH; ++q)
                         if (k2[q0 + q] != 0xffffffffu)
+#ifdef FL_X_SCATTER_READS   /* timing experiment (wrong results): a plain read of the cursor instead of the returning add */
+                            pos[q] = (my_cnt[k2[q0 + q]] + (uint32_t)(q0 + q) * NT + tid) & (uint32_t)(FL_BIN_R_MAX * NT - 1);
+#else
                             pos[q] = __hip_atomic_fetch_add(my_cnt + k2[q0 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < FL_SCATTER_DEPTH; ++q)
+#if defined(FL_X_NO_SCAN)
+                        if (k2[q0 + q] != 0xffffffffu) stage[pos[q] & (uint32_t)(FL_BIN_R_MAX * NT - 1)] = r2[q0 + q] & ((1u << PAY_BITS) - 1u);
+#else
                         if (k2[q0 + q] != 0xffffffffu) stage[pos[q]] = r2[q0 + q] & ((1u << PAY_BITS) - 1u);
+#endif
                 }
+#endif
                 __syncthreads();
+#ifdef FL_X_NO_PACK         /* timing experiment (wrong results) */
+                const uint32_t nvalid = 0;
+#else
                 const uint32_t nvalid = *s_nvalid;
+#endif
                 if constexpr (PACK3) {
                     // three 21-bit records to an aligned 64-bit word (flame_device.h): the log is what the accumulate streams, and at
                     // 1080p it is bound by those bytes.  The slots behind the batch's last record hold whatever the LDS held (the
@@ -808,14 +886,23 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
                 for (uint32_t i = tid; i < SETS * CNTW; i += NT) cnt[i] = 0;               // the cursors become counters again
                 ++batch_in_slot;
                 __syncthreads();
-            }
+            };
+#if FL_SORT_FULL_COPY
+            if (blen == (uint32_t)FL_BIN_R_MAX) sort_batch((uint32_t)FL_BIN_R_MAX); else
+#endif
+            sort_batch(blen);
     }
     }
 
     if (ACC == 0) drain_if_full(pend_ok, pend_old, pend_gi, pend_mult, atom, out4, n_spill);
     else if (pend_old == 0x123456789abcdefull) atom[0] = pend_old;
-    points[wi] = make_float4(x, y, color, 0.0f);                            // iter.py:414-416
-    rng[wi].mul = rctx.mul; rng[wi].state = rctx.state; rng[wi].carry = rctx.carry;
+    {   // (the walker's index again, behind an empty asm: two 64-bit addresses are not held across the kernel)
+        uint32_t tid_end = threadIdx.x;
+        asm volatile("" : "+v"(tid_end));
+        const size_t wj = (size_t)slot * NT + tid_end;
+        points[wj] = make_float4(x, y, color, 0.0f);                        // iter.py:414-416
+        rng[wj].mul = rctx.mul; rng[wj].state = rctx.state; rng[wj].carry = rctx.carry;
+    }
 
     if (COUNT) {
         atomicAdd(counters + 0, (u64)n_acc);
@@ -836,6 +923,9 @@ iter_body(unsigned char *smem, const int32_t *__restrict__ prog, const float *__
 #ifdef FL_RTC
 // the kernel of ONE genome structure, walker geometry and accumulate mode (rtc.hip compiles it on
 // first use and caches the code object)
+#ifdef FL_X_WAVES_PER_EU    /* experiment: cap the vector registers (8: 64, 7: 72, 6: 80 ...) */
+__attribute__((amdgpu_waves_per_eu(FL_X_WAVES_PER_EU, FL_X_WAVES_PER_EU)))
+#endif
 extern "C" __global__ void __launch_bounds__(FL_SPEC_NW * 64) k_iter_spec(FL_ITER_ARGS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

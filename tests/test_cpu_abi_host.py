@@ -237,6 +237,36 @@ def test_per_genome_kernel_compiles(built, cfg):
         assert rc == 0, log.value.decode()[:3000]
 
 
+@pytest.mark.parametrize('cfg,limit', [('cfg2', 64), ('cfg3', 64), ('cfg5', 64)])
+def test_per_genome_binned_kernel_register_budget(built, tmp_path, monkeypatch, cfg, limit):
+    """The four-wave binned per-genome kernel of the 1080p configs fits 64 vector registers with no scratch (round 6: the batch
+    epilogue derives its addresses from a thread number it takes anew — held across the kernel as loop invariants they made it
+    79; rtc.hip's limits are 128 / 80 for the 1024- / 1536-slot geometries), the twelve heavy xforms of cfg5 included."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    from cuburn_amd import _lib, configs
+    from cuburn_amd.packer import GenomePacker
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not os.path.exists(readelf):
+        pytest.skip('no llvm-readelf')
+    monkeypatch.setenv('FLAME_RTC_DUMP', str(tmp_path))
+    monkeypatch.delenv('FLAME_RTC_FLAGS', raising=False)
+    lib = _lib.load()
+    gnm, prof = configs.CONFIGS[cfg]()
+    pk = GenomePacker(gnm)
+    prog = np.ascontiguousarray(pk.prog, np.int32)
+    ops = np.ascontiguousarray(pk.ops_array, np.int32)
+    log = C.create_string_buffer(8192)
+    rc = lib.fl_rtc_compile_check(prog.ctypes.data, len(prog), ops.ctypes.data, len(ops), 4, 0, 1, log, len(log))
+    if rc == _lib.FL_E_UNSUPPORTED:
+        pytest.skip('libhiprtc is not installed')
+    assert rc == 0, log.value.decode()[:3000]
+    notes = subprocess.run([readelf, '--notes', str(tmp_path / 'k_iter_spec.co')], capture_output=True, text=True, timeout=60).stdout
+    num = lambda key: int(re.search(r'\.' + key + r':\s+(\d+)', notes).group(1))
+    assert num('vgpr_count') <= limit and num('vgpr_spill_count') == 0 and num('private_segment_fixed_size') == 0, notes[-1500:]
+
+
 def test_asm_issued_loads_are_not_touched_in_flight(tmp_path):
     """k_accum_tiles issues its record loads and the tile add's returning atomics from inline asm and
     waits for them itself (binned.hip: ACC_PIPE, ACC_ADD_ILP), so the compiler does not know those

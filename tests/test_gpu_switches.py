@@ -32,7 +32,10 @@ np.save(%(out)r, np.stack(frames))
 SWITCHES = [('FLAME_LANES', '1'), ('FLAME_LANES', '3'), ('FLAME_LANES', '4'), ('FLAME_NO_INTRA_OVERLAP', '1'),
             ('FLAME_DE_ORDER', '0'), ('FLAME_DE_ORDER', '1'), ('FLAME_DE_ORDER', '2'), ('FLAME_DE_ORDER', '01201201'),
             ('FLAME_BIN_GANG', '32'), ('FLAME_BIN_GANG', '4'), ('FLAME_BIN_PARTS', '5'), ('FLAME_BIN_ROUNDS', '8'),
-            ('FLAME_LAUNCH_ROUNDS', '64'), ('FLAME_BIN_WIDE', '1'), ('FLAME_RTC', '0')]
+            ('FLAME_LAUNCH_ROUNDS', '64'), ('FLAME_BIN_WIDE', '1'), ('FLAME_RTC', '0'),
+            # code-generation switches of the per-genome kernel (round 6): the plot of a round inside the next round's xform block
+            # or behind its own walk; the batch epilogue compiled once, for any batch length
+            ('FLAME_RTC_FLAGS', '-DFL_ITER_MERGE_MAX_XF=0'), ('FLAME_RTC_FLAGS', '-DFL_SORT_FULL_COPY=0 -DFL_SORT_LOCAL_TID=0')]
 
 
 def render_with(tmp_path, tag, env):
