@@ -100,11 +100,11 @@ def leaf(xf, path):
     return float(d)
 
 
-def run_case(ref_iter, xf, pts, rng, workdir, tag):
+def run_case(ref_iter, stdlib_decls, xf, pts, rng, workdir, tag):
     root = Root(xf)
     body = ref_iter.iter_xf_body(None, '0', View(root, ('px',)))
     inputs = sorted(root.used - root.derived)
-    src = [PRELUDE]
+    src = [PRELUDE, stdlib_decls]       # (the reference's M_PI ... are single-precision literals, cuburn/code/util.py:141-170)
     for p in inputs:
         src.append('static const float %s = %sf;' % ('_'.join(p), repr(float(np.float32(leaf(xf, p))))))
     for p in sorted(root.derived):
@@ -144,7 +144,7 @@ int main() {
 
 def main():
     tmp, dst = MG.prepare_reference()
-    from cuburn.code import iter as ref_iter
+    from cuburn.code import iter as ref_iter, util as ref_util
     from cuburn.genome import variations as ref_vars
     from cuburn_amd import configs
     work = tempfile.mkdtemp(prefix='xf_apply_')
@@ -177,7 +177,7 @@ def main():
         pts[:, 2] = rs.uniform(0, 1, NPTS)
         rng = np.stack([rs.randint(1 << 16, 1 << 32, NPTS, dtype=np.uint64), rs.randint(1, 0x7fffffff, NPTS, dtype=np.uint64),
                         rs.randint(1, 0x7fffffff, NPTS, dtype=np.uint64)], 1).astype(np.uint32)
-        out = run_case(ref_iter, xf, pts, rng, work, 'xf_%03d' % k0)
+        out = run_case(ref_iter, ref_util.stdlib.decls, xf, pts, rng, work, 'xf_%03d' % k0)
         b64 = lambda a: base64.b64encode(np.ascontiguousarray(a, '<u4').tobytes()).decode()
         cases.append({'variations': vnames, 'xform': xf,                 # arrays: little-endian uint32, base64, row-major
                       'points_in': b64(pts.view(np.uint32)), 'rng_in': b64(rng),            # [npts][x y colour], [npts][mul state carry]
