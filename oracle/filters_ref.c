@@ -8,6 +8,11 @@
  * interleaved floats.  Texture reads are POINT-sampled with unnormalised coordinates,
  * for which CUDA clamps to the edge whatever address mode was requested
  * (cuburn/code/util.py:55-60; SURVEY.md §7 "Texture semantics").
+ *
+ * PINNED BY THE REFERENCE'S OWN KERNELS: tests/golden/make_golden_filters.py compiles the assembled CUDA text of
+ * cuburn/code/filters.py + color.py as host C++ (a CUDA stand-in, the reference's launch shape and launch order)
+ * and tests/test_cpu_golden.py::test_filter_kernels_match_reference_kernels holds every function below to its
+ * outputs — 34 kernel outputs, equal to the last bit.
  */
 #include "flame_ref.h"
 #include <math.h>

@@ -12,6 +12,12 @@
  * operations the same way.  Transcendentals use libm here (the device uses fast
  * hardware approximations, as the reference does under -use_fast_math,
  * cuburn/code/util.py:96), so flames using them are compared distributionally.
+ *
+ * PINNED BY THE REFERENCE'S OWN TEMPLATES (xform application): tests/golden/make_golden_xf.py renders the
+ * reference's apply_xf template and its 95 variation entries, compiles them as host C++ and
+ * tests/test_cpu_golden.py::test_xform_application_matches_reference_templates holds ref_apply_xf to the results
+ * (RNG streams bit-exact, points 1e-4).  The sample loop around it (swap, packed-cell add, drain, flush) stands on
+ * reading: parity of that part is unpinned by reference outputs.
  */
 #include "flame_ref.h"
 #include <math.h>
