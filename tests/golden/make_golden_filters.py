@@ -43,6 +43,7 @@ PRELUDE = r'''
 #define __constant__ static
 #define __shared__ static
 #define __syncthreads() ((void)0)
+#define __noinline__
 struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
