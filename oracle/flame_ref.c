@@ -16,8 +16,11 @@
  * PINNED BY THE REFERENCE'S OWN TEMPLATES (xform application): tests/golden/make_golden_xf.py renders the
  * reference's apply_xf template and its 95 variation entries, compiles them as host C++ and
  * tests/test_cpu_golden.py::test_xform_application_matches_reference_templates holds ref_apply_xf to the results
- * (RNG streams bit-exact, points 1e-4).  The sample loop around it (swap, packed-cell add, drain, flush) stands on
- * reading: parity of that part is unpinned by reference outputs.
+ * (RNG streams bit-exact, points 1e-4); the packed-cell add with its drain and the flush are held to the reference's inline
+ * PTX, interpreted by tests/golden/ptx_mini.py (bit-exact; hot-flag codes 1 and 2 are exchanged there, see
+ * test_packed_cell_add_and_flush_match_reference_ptx); parameter blocks and packed palettes to the reference's generated interp
+ * kernels.  The control flow around these pieces (xform choice, swap, bounds test) stands on reading: parity of that part is
+ * unpinned by reference outputs.
  */
 #include "flame_ref.h"
 #include <math.h>
@@ -695,6 +698,33 @@ static void spill_cell(uint64_t cell, float mult, float *o4)   /* iter.py:383-40
     o4[3] += (float)u[3] * mult;
 }
 
+/* One sample into the packed histogram (cuburn/code/iter.py:332-411, the checked path on every add): the palette cell of the
+ * dithered colour index is added to the pixel's packed cell; a cell seen at 512 hits or more is taken out whole and added to
+ * the float accumulator.  Returns 1 if it drained the cell. */
+static inline int plot_cell(const uint64_t *palrow, uint32_t gi, float cc, float dither, float mult, uint64_t *atom, float *out4)
+{
+    float cf = fmaf(cc, 255.0f, dither);                             /* iter.py:346-348 */
+    int ci = (cf != cf) ? 0 : (cf >= 255.0f ? 255 : (cf <= 0.0f ? 0 : (int)rintf(cf)));
+    uint64_t val = palrow[ci];                                       /* iter.py:351 (clamped surface read) */
+    uint64_t old = atom[gi];
+    atom[gi] = old + val;                                            /* iter.py:355-363 */
+    if ((uint32_t)(old >> 32) >= (256u << 23)) {                     /* iter.py:369-379 checked path */
+        spill_cell(atom[gi], mult, &out4[4 * (size_t)gi]);
+        atom[gi] = 0;
+        return 1;
+    }
+    return 0;
+}
+
+/* Test hook: plot_cell on explicit samples, in order (tests/test_cpu_golden.py holds it to the reference's own PTX run through
+ * tests/golden/ptx_mini.py).  `palette` is [64][256] packed cells, `row[i]` the palette row (temporal sample) of sample i. */
+void ref_plot_samples(uint32_t n, const uint32_t *gi, const float *cc, const float *dither, const uint32_t *row,
+                      const float *mult, const uint64_t *palette, uint64_t *atom, float *out4)
+{
+    for (uint32_t i = 0; i < n; ++i)
+        plot_cell(palette + (size_t)row[i] * 256, gi[i], cc[i], dither[i], mult[i], atom, out4);
+}
+
 /* One workgroup of the device model (cuburn/code/iter.py:157-418, adapted as documented in
  * DESIGN.md §iterate): walkers are bound to their slot, the per-wave selector is lane 0's
  * draw, fuse is a property of the launch, hot flags are 2 bits/pixel at word gi>>4. */
@@ -763,17 +793,8 @@ static int iter_block(const ref_geom *g, const ref_dim *dim, const int32_t *prog
                 mult = hot_mult(flag);
                 if (ref_mwc_next_01(&rng[t]) > 1.0f / mult) { ctr[2]++; continue; }
             }
-            float cf = fmaf(cc, 255.0f, dith[t]);                    /* iter.py:346-348 */
-            int ci = (cf != cf) ? 0 : (cf >= 255.0f ? 255 : (cf <= 0.0f ? 0 : (int)rintf(cf)));
-            uint64_t val = palrow[ci];                               /* iter.py:351 (clamped surface read) */
-            uint64_t old = atom[gi];
-            atom[gi] = old + val;                                    /* iter.py:355-363 */
             ctr[0]++;
-            if ((uint32_t)(old >> 32) >= (256u << 23)) {             /* iter.py:369-379 checked path */
-                spill_cell(atom[gi], mult, &out4[4 * (size_t)gi]);
-                atom[gi] = 0;
-                ctr[3]++;
-            }
+            ctr[3] += plot_cell(palrow, gi, cc, dith[t], mult, atom, out4);
         }
     }
     free(sx); free(dith); free(sel); free(sel_next);

@@ -62,6 +62,8 @@ int ref_iter_launch(const ref_geom *g, const ref_dim *dim, const int32_t *prog, 
 
 /* cuburn/code/iter.py:420-544 */
 void ref_flush(const ref_dim *dim, uint64_t *atom, float *out4, uint32_t *hot);
+void ref_plot_samples(uint32_t n, const uint32_t *gi, const float *cc, const float *dither, const uint32_t *row,
+                      const float *mult, const uint64_t *palette, uint64_t *atom, float *out4);
 void ref_unpack_cell(uint64_t cell, uint32_t out[4]);
 
 /* flam3-style per-sample-selection chaos game: CPU baseline */
