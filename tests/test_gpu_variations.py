@@ -124,3 +124,47 @@ def test_variation_matches_oracle(mgr, name):
             unexplained.append(int(i))
     assert not unexplained, (name, 'points off the oracle at a well-conditioned input', unexplained[:5],
                              pts[unexplained[:3]], d[unexplained[:3]], r[unexplained[:3]])
+
+
+def _ref_cases():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'xf_apply.json')) as fp:
+        g = json.load(fp)
+    return g['npts'], g['cases']
+
+
+@pytest.mark.parametrize('idx', range(99))
+def test_xform_application_matches_reference_templates(mgr, idx):
+    """The HIP xform application against vectors computed by the REFERENCE's own ``apply_xf`` template and variation entries
+    (tests/golden/xf_apply.json, made by tests/golden/make_golden_xf.py: rendered and compiled as host C++), without the oracle in
+    between: one xform per variation with every parameter off its default (every other one with a post affine), four xforms that
+    sum three variations, 32 points each.  RNG streams bit-exact (same draws in the same order), colour to an ulp, points to the
+    bar of the oracle comparison above (2e-3 relative / 2e-4 absolute: single hardware instructions for sin / cos / exp / log /
+    rcp / sqrt) with at most 3 of 32 points of an ill-conditioned variation within 5 %."""
+    import base64
+    n, cases = _ref_cases()
+    case = cases[idx]
+    dec = lambda s, c: np.frombuffer(base64.b64decode(s), '<u4').reshape(n, c).copy()
+    lib = _lib.load()
+    gnm = {'type': 'animation', 'camera': {'scale': 0.25}, 'time': {'duration': 1, 'frame_width': 0.0},
+           'palette': [[0.0] + configs.palette_encode(configs.grey_ramp())], 'xforms': {'0': dict(case['xform'], weight=1.0)}}
+    prof = {'width': 64, 'height': 64, 'spp': 1, 'fps': 1, 'duration': 1, 'frame_width': 0}
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    _lib.check(lib.fl_interp(mgr.fb.ctx, g, 64, 64, 0.5, 0.0))
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, :3] = dec(case['points_in'], 3).view(np.float32)
+    rng = dec(case['rng_in'], 3)
+    _lib.check(lib.fl_debug_apply_xf(mgr.fb.ctx, g, 5, 0, n, pts.ctypes.data, rng.ctypes.data))
+    want, want_rng = dec(case['points_out'], 3).view(np.float32), dec(case['rng_out'], 2)
+    assert np.array_equal(rng[:, 1:], want_rng), 'random draws differ in number or order'
+    assert np.abs(pts[:, 2] - want[:, 2]).max() <= 2.5e-7, 'colour blend'
+    a, b = pts[:, :2].astype(np.float64), want[:, :2].astype(np.float64)
+    fin = np.isfinite(b).all(1) & (np.abs(b).max(1) < 1e6)
+    assert np.isfinite(a[fin]).all()
+    err = np.abs(a[fin] - b[fin]) - (2e-4 + 2e-3 * np.abs(b[fin]))
+    loose = np.abs(a[fin] - b[fin]) - (2e-4 + 5e-2 * np.abs(b[fin]))
+    nbad = int((err > 0).any(1).sum())
+    assert nbad <= 3 and not (loose > 0).any(), ('+'.join(case['variations']), nbad, a[fin][(err > 0).any(1)][:3], b[fin][(err > 0).any(1)][:3])
