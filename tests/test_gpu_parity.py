@@ -1545,3 +1545,119 @@ def test_filters_match_reference_kernel_vectors(mgr):
     assert_close(dev[pos], g['out_colorclip'], 1e-3, 1e-5, 'colorclip vs reference kernel')
     dev = run_filter(mgr, 'bilateral', dim, img, list(a[3:8]))
     assert_close(dev[pos], g['out_bilateral_chain'], 2e-3, 2e-4, 'bilateral chain vs reference kernel')
+
+
+@pytest.mark.parametrize('cfg', ['cfg3', 'cfg5', 'allvars'])
+def test_interp_params_match_reference_interp_kernel(mgr, cfg):
+    """``fl_interp``'s parameter blocks against the blocks the REFERENCE's own generated ``interp_iter_params`` kernel wrote
+    (tests/golden/interp_params.npz, tests/golden/make_golden_interp.py), by field name, without the oracle in between: device
+    splines (linear and magnitude domain), camera, affine, density and variation precalc for 12 temporal samples.  2e-5 relative
+    (+ the pixel-scale camera offsets' 1e-5 absolute), the bar of the oracle comparison above."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'interp_params.npz'))
+    gnm, prof = configs.allvars() if cfg == 'allvars' else configs.CONFIGS[cfg]()
+    w, h = [int(v) for v in gold[cfg + '_dim'][:2]]
+    gprof = profile.wrap(dict(prof, width=w, height=h), gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    dim = mgr.fb.calc_dim(w, h)
+    times = gold[cfg + '_times']
+    tstep = np.float32(times[1] - times[0])
+    ns = mgr.fb.nslots
+    _lib.check(_lib.load().fl_interp(mgr.fb.ctx, g, dim.w, dim.h, float(times[0]), float(np.float32(tstep * np.float32(ns)))))
+    dev = mgr.fb.read('params', (ns, rdr.packer.pstride), np.float32, g)
+    names = ['.'.join(n) for n in rdr.packer.packed]
+    blocks = gold[cfg + '_blocks']
+    for j, rn in enumerate(str(x) for x in gold[cfg + '_names']):
+        key = 'den.' + rn[4:] if rn.startswith('den_') else rn
+        k = names.index(key)
+        got, want = dev[:len(times), k].astype(np.float64), blocks[:, j].astype(np.float64)
+        err = np.abs(got - want) / (np.abs(want) + 1.0)
+        assert err.max() < 2e-5, (cfg, rn, got[np.argmax(err)], want[np.argmax(err)])
+
+
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'allvars'])
+def test_palette_matches_reference_kernel(mgr, cfg):
+    """The packed palette and the RNG states behind it against the REFERENCE's own ``interp_palette_flat`` kernel
+    (tests/golden/interp_palette.npz), bit for bit (sha256 of the 64 x 256 cells and of the 16384 states after; four rows in full),
+    without the oracle in between."""
+    import hashlib, os
+    from cuburn_amd import mwc as my_mwc
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'interp_palette.npz'))
+    gnm, prof = configs.allvars() if cfg == 'allvars' else small(configs.CONFIGS[cfg], 640, 360)
+    ns, nt, nwalk, _ = walkers(mgr)
+    seeds = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)
+    seeds[nwalk:] = my_mwc.make_seeds(64 * 256, int(gold['host_seed']))
+    mgr.fb.write('seeds', seeds)
+    gprof = profile.wrap(prof, gnm)
+    rdr = render.Renderer(gnm, gprof)
+    g = rdr._handle(mgr.fb)
+    mgr._copy(rdr, gnm)
+    dim = mgr.fb.calc_dim(gprof.width, gprof.height)
+    ts, td = [float(v) for v in gold[cfg + '_ts_td']]
+    _lib.check(_lib.load().fl_interp(mgr.fb.ctx, g, dim.w, dim.h, ts, td))
+    dev = mgr.fb.read('palette', (64, 256), np.uint64)
+    np.testing.assert_array_equal(dev[[0, 1, 31, 63]], gold[cfg + '_packed_rows'])
+    assert hashlib.sha256(np.ascontiguousarray(dev).tobytes()).hexdigest() == str(gold[cfg + '_packed_sha256'])
+    after = mgr.fb.read('seeds', (nwalk + 64 * 256, 3), np.uint32)[nwalk:]
+    assert hashlib.sha256(np.ascontiguousarray(after).tobytes()).hexdigest() == str(gold[cfg + '_rng_after_sha256'])
+
+
+def test_flush_matches_reference_ptx(mgr):
+    """``k_flush`` against the REFERENCE's own flush_atom PTX (tests/golden/ptx_cells.npz: the packed cells and the float
+    accumulator after 6000 adds by the reference's PTX, then its flush, all through tests/golden/ptx_mini.py), without the oracle
+    in between: the float accumulator after the flush is equal to the last bit, the hot flags agree cell for cell up to the
+    reference's exchanged codes 1 and 2 (see tests/test_cpu_golden.py::test_packed_cell_add_and_flush_match_reference_ptx)."""
+    import os
+    lib = _lib.load()
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ptx_cells.npz'))
+    dim = mgr.fb.calc_dim(36, 20)
+    S, AH = int(gold['astride']), int(gold['aheight'])
+    assert (dim.astride, dim.ah) == (S, AH)
+    ncell = S * AH
+    _lib.check(lib.fl_debug_clear(mgr.fb.ctx, dim.w, dim.h, 1))
+    _lib.check(lib.fl_debug_clear_hot(mgr.fb.ctx, dim.w, dim.h))
+    mgr.fb.write('atom', np.ascontiguousarray(gold['atom_after_add'], np.uint64))
+    mgr.fb.write('front', np.ascontiguousarray(gold['out_after_add'], np.float32))
+    hot = np.zeros((ncell + 15) // 16, np.uint32)
+    for cell, f in gold['hot_cells']:
+        hot[cell >> 4] |= np.uint32(int(f) << ((int(cell) & 15) << 1))
+    mgr.fb.write('hot', hot)
+    _lib.check(lib.fl_debug_flush(mgr.fb.ctx, dim.w, dim.h))
+    out = mgr.fb.read('front', (ncell, 4), np.float32)
+    np.testing.assert_array_equal(out, gold['out_after_flush'])
+    assert not mgr.fb.read('atom', (ncell,), np.uint64).any()
+    hot2 = mgr.fb.read('hot', hot.shape, np.uint32)
+    flags = np.array([(int(hot2[c >> 4]) >> ((c & 15) << 1)) & 3 for c in range(ncell)], np.uint8)
+    np.testing.assert_array_equal(np.array([0, 2, 1, 3], np.uint8)[flags], gold['flags_after_flush'])
+
+
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3'])
+def test_histogram_matches_reference_iterate_kernel(mgr_prod, cfg):
+    """The GPU's histogram (the default binned path, the production walker geometry) against the histogram the REFERENCE's own
+    ``iter`` kernel computed when run on the host (tests/golden/iter_hist.npz, tests/golden/make_golden_iter.py: a block's threads
+    as coroutines, 134 M samples), without the oracle in between: cfg2's and cfg3's flames at 320 x 180 over the same frame
+    window.  Different random streams: the fraction of samples in frame within 0.3 %, the density over 8 x 8 blocks within 2 % L1
+    (wave-coherent xform choice is cluster sampling in both; the shot-noise floor of the two samples is 0.4 %), the mean colour
+    within 1 / 255."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'iter_hist.npz'))
+    mgr = mgr_prod
+    w, h = [int(v) for v in gold[cfg + '_size']]
+    gnm, prof = small(configs.CONFIGS[cfg], w, h, samples=2 ** 27)
+    rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof, 0.5)
+    lib = _lib.load()
+    run = C.c_uint64()
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 27), 256, _lib.ACCUM_BINNED, C.byref(run)))
+    front = mgr.fb.read('front', (dim.ah * dim.astride, 4), np.float32)
+    n_ref, plotted, _ = [int(v) for v in gold[cfg + '_counts']]
+    H, W = dim.ah // 8 * 8, dim.astride // 8 * 8
+    b = front.reshape(dim.ah, dim.astride, 4).astype(np.float64)[:H, :W].reshape(H // 8, 8, W // 8, 8, 4).sum((1, 3))
+    a = gold[cfg + '_blocks8'].astype(np.float64)
+    assert a.shape == b.shape
+    assert abs(plotted / n_ref - front[:, 3].astype(np.float64).sum() / run.value) < 3e-3
+    pa, pb = a[..., 3] / a[..., 3].sum(), b[..., 3] / b[..., 3].sum()
+    assert np.abs(pa - pb).sum() < 0.02, float(np.abs(pa - pb).sum())
+    ca, cb = a[..., :3].sum((0, 1)) / a[..., 3].sum(), b[..., :3].sum((0, 1)) / b[..., 3].sum()
+    assert np.abs(ca - cb).max() < 1.0 / 255, (ca, cb)
