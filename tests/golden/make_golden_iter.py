@@ -15,9 +15,9 @@ histogram (cuburn/code/iter.py:157-418).  Here that text runs on the host, unmod
     chunks of points / RNG states; every chunk is used three times, its first use is the un-plotted "fuse" pass (iter.py:207-215).
 The parameter blocks come from the same module's ``interp_iter_params`` run first; the packed palette from the oracle's
 ``interp_palette`` (pinned bit-exactly to the reference's kernel by interp_palette.npz).
-Kept (iter_hist.npz), for cfg2 and cfg3 at 320 x 180: 8 x 8-block sums of the flushed accumulator (density and colour sums), the
+Kept (iter_hist.npz), for cfg2, cfg3 and cfg5 at 320 x 180: 8 x 8-block sums of the flushed accumulator (density and colour sums), the
 number of samples attempted and plotted.
-    python tests/golden/make_golden_iter.py          (in the build container: needs /root/reference and g++; about three minutes)
+    python tests/golden/make_golden_iter.py          (in the build container: needs /root/reference and g++; about five minutes)
 """
 import os
 import re
@@ -133,7 +133,7 @@ def main():
     from cuburn_amd import configs
     from common import O, oracle_palette
     out = {}
-    for name in ('cfg2', 'cfg3'):
+    for name in ('cfg2', 'cfg3', 'cfg5'):
         gnm, prof = configs.CONFIGS[name]()
         prof = dict(prof, width=320, height=180)
         run_genome(name, gnm, prof, ref_iter, util, ref_mwc, render, O, oracle_palette, out)

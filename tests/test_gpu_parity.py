@@ -1633,11 +1633,11 @@ def test_flush_matches_reference_ptx(mgr):
     np.testing.assert_array_equal(np.array([0, 2, 1, 3], np.uint8)[flags], gold['flags_after_flush'])
 
 
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3'])
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg5'])
 def test_histogram_matches_reference_iterate_kernel(mgr_prod, cfg):
     """The GPU's histogram (the default binned path, the production walker geometry) against the histogram the REFERENCE's own
     ``iter`` kernel computed when run on the host (tests/golden/iter_hist.npz, tests/golden/make_golden_iter.py: a block's threads
-    as coroutines, 134 M samples), without the oracle in between: cfg2's and cfg3's flames at 320 x 180 over the same frame
+    as coroutines, 134 M samples), without the oracle in between: cfg2's, cfg3's and cfg5's flames at 320 x 180 over the same frame
     window.  Different random streams: the fraction of samples in frame within 0.3 %, the density over 8 x 8 blocks within 2 % L1
     (wave-coherent xform choice is cluster sampling in both; the shot-noise floor of the two samples is 0.4 %), the mean colour
     within 1 / 255."""
