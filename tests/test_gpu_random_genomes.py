@@ -112,7 +112,17 @@ def random_genome(seed):
     return gnm, prof
 
 
-@pytest.mark.parametrize('seed', list(range(1, 49)))
+def _seeds():
+    """1 .. 48 by default; FLAME_SOAK_SEEDS=a-b widens the range for a soak run (profiles/r06_soak_random_genomes.txt: 49-248)."""
+    import os
+    e = os.environ.get('FLAME_SOAK_SEEDS')
+    if e:
+        a, b = e.split('-')
+        return list(range(int(a), int(b) + 1))
+    return list(range(1, 49))
+
+
+@pytest.mark.parametrize('seed', _seeds())
 def test_random_genome_parity(mgr, mgr_prod, seed):
     lib = _lib.load()
     gnm, prof = random_genome(seed)
