@@ -533,8 +533,8 @@ def main():
                          'k_accum_tiles_ms_per_frame': round(acc['accum_ms'] / ksteps, 4),
                          'k_flush_ms_per_frame': round(acc['flush_only_ms'] / ksteps, 4),
                          'note': ('kernel times: one stream lane, the frame loop\'s walker geometry (%d slots).  For frames of up to 2^28 samples the loop '
-                                  'runs 1024 slots: a third fewer un-plotted fuse iterations, the PIPELINE ~4 %% faster, this chain ALONE ~5 %% slower '
-                                  'than at 1536 slots (FLAME_NSLOTS=1536; profiles/r03_slots_by_samples.txt)' % mgr.fb.nslots)},
+                                  'runs 1024 slots, up to 2^30 samples 1280, above 1536: fewer un-plotted fuse iterations and LDS left for the other lane; the PIPELINE '
+                                  '3-6 %% faster, this chain ALONE ~5 %% slower than at 1536 slots (FLAME_NSLOTS=1536; profiles/r06_experiments.txt section 17)' % mgr.fb.nslots)},
             'de_filter': {'kernels': '8 x k_de_dir (the first normalises the accumulator, the last un-normalises and tone-maps)', 'ms_per_frame': round(de_s * 1e3, 4),
                           'gbps': round(de_gbs, 2), 'frac_of_peak': round(de_gbs / HBM_PEAK_GBS, 5),
                           'measured_copy_gbps': round(copy_gbs, 1) if copy_gbs else None,

@@ -99,6 +99,12 @@ class Framebuffers(object):
     # stream lane's kernels run beside it.  With more samples the second launch costs more than the fuse saves
     # (profiles/r03_slots_by_samples.txt).  Decided per frame from its sample count (set_dim).
     NARROW_FEW = (4, 1024)
+    # ... and 1280 slots for frames of 2^28 .. 2^30 samples (round 6): six iterate workgroups per CU hold 155 KB of its 160 KB of
+    # LDS and leave the other stream lane's kernels no room beside them, five leave 31 KB (profiles/r06_experiments.txt section 17:
+    # cfg3 at 2^29 / 2^30 samples 2.66 -> 2.51 / 4.56 -> 4.39 ms per frame, cfg2's flame 2.35 -> 2.26 / 4.02 -> 3.89; from 2^31
+    # samples on the walk itself decides and 1536 slots win by 0.4-1.7 %)
+    NARROW_MID = (4, 1280)
+    MID_SAMPLES = 2 ** 30
     # The same for the 8-wave geometry (round 5; since round 6 only through FLAME_NW=8 FLAME_NSLOTS=512): 512 slots whose two halves of four waves walk two temporal samples — the
     # reference's 1024 samples x 256 threads exactly, bit for bit the walkers of NARROW_FEW, sharing 8192-record sort batches
     # (csrc/iter.hip "Sub-blocks of four waves").  1024 slots of 8 waves walk 512 threads per sample: twice the un-plotted rounds.
@@ -176,12 +182,12 @@ class Framebuffers(object):
             if want == self.NARROW:
                 # decided per FRAME from its sample count, so that the GEOMETRY a frame is rendered with does not depend on
                 # what was rendered before it, on whichever rank (a context that last held the other geometry is re-created:
-                # 1024 <-> 1536 slots only changes when a job's samples per frame cross 2^28; the re-created context's RNG
+                # 1024 <-> 1280 <-> 1536 slots only changes when a job's samples per frame cross 2^28 / 2^30; the re-created context's RNG
                 # streams do depend on the number of switches, see `ctx`); without a sample count the small-image geometry
                 # in use is kept
                 if nsamples is not None:
-                    want = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW
-                elif self._cfg in (self.NARROW, self.NARROW_FEW):
+                    want = self.NARROW_FEW if nsamples <= self.FEW_SAMPLES else self.NARROW_MID if nsamples <= self.MID_SAMPLES else self.NARROW
+                elif self._cfg in (self.NARROW, self.NARROW_MID, self.NARROW_FEW):
                     want = self._cfg
             elif want == self.WIDE:
                 if nsamples is not None:

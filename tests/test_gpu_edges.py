@@ -278,7 +278,7 @@ def test_default_filter_chain_and_size_changes(mgr):
 
 def test_walker_geometry_follows_image_size():
     """A manager built without an explicit slot count uses 4-wave slots for small images — 1024 of
-    them for frames of up to 2^28 samples, 1536 above, decided per frame from its sample count (the GEOMETRY of a
+    them for frames of up to 2^28 samples, 1280 up to 2^30, 1536 above, decided per frame from its sample count (the GEOMETRY of a
     frame does not depend on what the context rendered before; its RNG streams do, as in the reference) —
     from ~1440p up 1024 8-wave slots for frames of more than 2^28 samples and 256 16-wave slots in quarters (a temporal sample per
     four waves) for frames of up to 2^28 — round 6: the 4K accumulate gains more from 16384-record batches than the walk loses —,
@@ -316,19 +316,19 @@ def test_walker_geometry_follows_image_size():
     # ... with RNG states of its own: the generation count is mixed into the seed (the reference's seed table lives as long as
     # its manager, render.py:95-104; round 4 re-seeded every re-created context identically)
     assert not np.array_equal(a, a2)
-    # 1024 <-> 1536 slots twice on one manager: the two 1024-slot frames, and the two 1536-slot frames, differ
+    # 1024 <-> 1280 slots twice on one manager: the two 1024-slot frames, and the two 1280-slot frames, differ
     many_m = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
     rdr_m = render.Renderer(gnm, many_m)
     flips = []
     for gp, rd in ((many_m, rdr_m), (small, rdr_s), (many_m, rdr_m), (small, rdr_s)):
         evt, f = m.queue_frame(rd, gnm, gp, 0.5); evt.synchronize()
         flips.append(((m.fb.nw, m.fb.nslots), np.array(f)))
-    assert [g for g, _ in flips] == [(4, 1536), (4, 1024), (4, 1536), (4, 1024)]
+    assert [g for g, _ in flips] == [(4, 1280), (4, 1024), (4, 1280), (4, 1024)]
     assert not np.array_equal(flips[1][1], flips[3][1]) and not np.array_equal(flips[0][1], flips[2][1])
     assert np.abs(flips[1][1].astype(np.float64) - flips[3][1]).mean() < 6.0
     # many samples per frame on a small image: the 1536-slot geometry the manager starts with stays
     q = render.RenderManager(device=0, host_seed=5)
-    many = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 28.5 / (640.0 * 360.0)), gnm)
+    many = profile.wrap(dict(prof, width=640, height=360, spp=2 ** 30.5 / (640.0 * 360.0)), gnm)
     evt, _ = q.queue_frame(render.Renderer(gnm, many), gnm, many, 0.5); evt.synchronize()
     assert (q.fb.nw, q.fb.nslots) == (4, 1536) and q.fb.generation == 0
     # ... and a frame of few samples after it gets the geometry it would have got as a first frame: the same pixels

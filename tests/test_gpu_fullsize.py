@@ -24,11 +24,11 @@ from cuburn_amd import configs, profile, render, _lib
 pytestmark = pytest.mark.gpu
 
 
-def iterate_frame(m, gnm, prof, tc, nsamples):
+def iterate_frame(m, gnm, prof, tc, nsamples, geometry_by_samples=False):
     lib = _lib.load()
     gprof = profile.wrap(prof, gnm)
     rdr = render.Renderer(gnm, gprof)
-    dim = m.fb.set_dim(gprof.width, gprof.height)
+    dim = m.fb.set_dim(gprof.width, gprof.height, nsamples=nsamples if geometry_by_samples else None)
     g = rdr._handle(m.fb)
     ts, td = frame_times(gprof, tc)
     fid = C.c_uint32()
@@ -138,8 +138,8 @@ def densest_window(dim, accum, AW, AH):
 def test_cfg3_full_size(built):
     gnm, prof = configs.cfg3()
     m = render.RenderManager(device=0, host_seed=42)
-    rdr, gprof, dim, td, nrun, front = iterate_frame(m, gnm, prof, 0.37, 2 ** 30)
-    assert (dim.w, dim.h) == (1920, 1080) and td > 0 and m.fb.nslots == 1536
+    rdr, gprof, dim, td, nrun, front = iterate_frame(m, gnm, prof, 0.37, 2 ** 30, geometry_by_samples=True)
+    assert (dim.w, dim.h) == (1920, 1080) and td > 0 and m.fb.nslots == 1280          # (2^30 samples: the geometry queue_frame picks, five workgroups per CU)
     assert nrun >= 2 ** 30 and nrun - 2 ** 30 < m.fb.nslots * 256
     check_against_cpu_game(gnm, prof, 0.37, m.fb.nslots, dim, front, nrun, 2 ** 27, 16, 0.02, 2e-3, 1.5 / 255)
     vals, dev = filter_chain_on_device(m, rdr, gprof, dim, 0.37)
