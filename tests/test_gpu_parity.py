@@ -1633,9 +1633,10 @@ def test_flush_matches_reference_ptx(mgr):
     np.testing.assert_array_equal(np.array([0, 2, 1, 3], np.uint8)[flags], gold['flags_after_flush'])
 
 
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg5'])
-def test_histogram_matches_reference_iterate_kernel(mgr_prod, cfg):
-    """The GPU's histogram (the default binned path, the production walker geometry) against the histogram the REFERENCE's own
+@pytest.mark.parametrize('cfg,mode', [('cfg2', 'binned'), ('cfg3', 'binned'), ('cfg5', 'binned'), ('cfg2', 'atomic')])
+def test_histogram_matches_reference_iterate_kernel(mgr_prod, cfg, mode):
+    """The GPU's histogram (the default binned path — and, for cfg2, the direct packed atomics, the reference's own scheme — at the
+    production walker geometry) against the histogram the REFERENCE's own
     ``iter`` kernel computed when run on the host (tests/golden/iter_hist.npz, tests/golden/make_golden_iter.py: a block's threads
     as coroutines, 134 M samples), without the oracle in between: cfg2's, cfg3's and cfg5's flames at 320 x 180 over the same frame
     window.  Different random streams: the fraction of samples in frame within 0.3 %, the density over 8 x 8 blocks within 2 % L1
@@ -1649,7 +1650,7 @@ def test_histogram_matches_reference_iterate_kernel(mgr_prod, cfg):
     rdr, gprof, dim, g, ts, td = setup_frame(mgr, gnm, prof, 0.5)
     lib = _lib.load()
     run = C.c_uint64()
-    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 27), 256, _lib.ACCUM_BINNED, C.byref(run)))
+    _lib.check(lib.fl_iterate(mgr.fb.ctx, g, dim.w, dim.h, float(2 ** 27), 256, _lib.ACCUM_BINNED if mode == 'binned' else _lib.ACCUM_ATOMIC, C.byref(run)))
     front = mgr.fb.read('front', (dim.ah * dim.astride, 4), np.float32)
     n_ref, plotted, _ = [int(v) for v in gold[cfg + '_counts']]
     H, W = dim.ah // 8 * 8, dim.astride // 8 * 8
